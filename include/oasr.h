@@ -1,0 +1,223 @@
+/*
+ * oasr.h — C ABI of liboasr_hip.so, the MI355X (gfx950) compute library behind
+ * omnilingual_asr's Pipeline.transcribe().
+ *
+ * The reference has no FFI for this path: its compute is one HTTPS call
+ * (ref:src/omnilingual_asr/models/inference/gemini_pipeline.py:512-530) and its only local
+ * stages are the duration gate and the fixed-length chunk plan (:217-219, :243-310, :713-714).
+ * Each entry point below names the reference behaviour it stands in for; stages the
+ * reference does not contain (log-mel features, conformer encoder) say so.
+ *
+ * Conventions
+ *   - every function returns 0 (OASR_OK) or a negative oasr_status; oasr_last_error() returns a
+ *     thread-local message for the last failure on the calling thread
+ *   - plain pointers and sizes only; device pointers are HIP device addresses owned by the
+ *     caller; `stream` is a hipStream_t passed as void* (NULL = the default stream)
+ *   - no function allocates or frees device memory, synchronises the device or blocks on the
+ *     stream, except oasr_encoder_create/destroy (host memory only) — so every launch function
+ *     may be captured into a hipGraph by the caller
+ *   - thread-compatible: no mutable global state; an encoder handle is immutable after create
+ */
+#ifndef OASR_H
+#define OASR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OASR_VERSION 100 /* 0.1.0 */
+
+typedef enum oasr_status {
+    OASR_OK = 0,
+    OASR_EINVAL = -1,   /* bad argument (null pointer, shape the kernels do not support) */
+    OASR_ECAPACITY = -2,/* caller-provided buffer too small */
+    OASR_EHIP = -3,     /* a HIP runtime call or kernel launch failed */
+    OASR_ENOMEM = -4    /* host allocation failed */
+} oasr_status;
+
+/* Feature geometry (fixed by the kernels). */
+#define OASR_SAMPLE_RATE 16000
+#define OASR_FRAME_LEN 400
+#define OASR_FRAME_HOP 160
+#define OASR_NFFT 512
+#define OASR_NMEL 80
+#define OASR_FEAT_DIM 160 /* two stacked frames */
+
+int oasr_version(void);
+const char* oasr_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Chunk plan (host, integer).  Replaces the plan computed inside split_audio_into_chunks
+ * (ref gemini_pipeline.py:256-310: `start=0; while start<total: emit; start+=chunk`, last chunk
+ * short, no overlap) together with the strict duration gate `duration > MIN` (ref :713-714).
+ * Writes (start_sample, end_sample) pairs into out_bounds[2*i], out_bounds[2*i+1].
+ * total_samples <= 0 yields the single entry (0, 0), as the reference returns the whole file
+ * when it cannot determine a duration (ref :257-259).
+ * Returns OASR_OK and stores the chunk count in *n_chunks; OASR_ECAPACITY (with *n_chunks set to
+ * the required count) when capacity_chunks is too small. */
+int oasr_plan_chunks(int64_t total_samples, int32_t sample_rate, double chunk_seconds,
+                     double min_chunking_seconds, int64_t* out_bounds, int64_t capacity_chunks,
+                     int64_t* n_chunks);
+
+/* Contiguous shard [lo, hi) of n_items owned by `rank` of `world` (first n%world ranks own one
+ * more).  Stands in for the reference's order-independent fan-out over chunks
+ * (ref gemini_pipeline.py:623-641), whose results are re-ordered only at merge (:647-654). */
+int oasr_shard_range(int64_t n_items, int32_t world, int32_t rank, int64_t* lo, int64_t* hi);
+
+/* Number of 25 ms frames (hop 10 ms, no centring) in n_samples, and of stacked frame pairs. */
+int64_t oasr_num_frames(int64_t n_samples);
+int64_t oasr_num_stacked(int64_t n_samples);
+
+/* ---------------------------------------------------------------------------------------------
+ * Log-mel features.  NOT IN THE REFERENCE (it uploads the file bytes instead,
+ * ref gemini_pipeline.py:340-362); geometry declared by this library: x*2^15, frame 400 / hop
+ * 160, per-frame DC removal, pre-emphasis 0.97, Povey window, 512-point power spectrum, 80
+ * Kaldi-mel triangles 20..8000 Hz, ln(max(.,2^-23)).
+ *
+ * Host copies of the constant tables the kernel uses (for checking): window[400],
+ * mel_weights[257*80] row-major [bin][filter]. */
+int oasr_logmel_tables(float* window, float* mel_weights);
+
+/* The same tables (plus FFT twiddles and the sparse form of the mel triangles) packed as the
+ * device blob the kernel reads.  The library keeps no device-side state: the caller copies the
+ * blob to each device once and passes its device address to oasr_logmel_f32. */
+int64_t oasr_logmel_table_words(void);
+int oasr_logmel_table_blob(uint32_t* blob, int64_t capacity_words);
+
+/* pcm        device, float32, B rows of `pcm_stride` samples; row b holds n_samples[b] valid
+ *            samples in [-1, 1]
+ * n_samples  device, int32[B]
+ * logmel     device, float32 [B][frame_cap][80]; rows >= num_frames(n_samples[b]) are left
+ *            untouched
+ * tables     device copy of oasr_logmel_table_blob()
+ * stats      device, float32 [B][stats_slots][80][2]: per work-group (mean, M2) partials of the
+ *            frames it produced, consumed by oasr_feature_norm_stack;
+ *            stats_slots = oasr_logmel_stats_slots(frame_cap); the last slot is reserved for the
+ *            merged (mean, 1/std) that oasr_feature_norm_stack writes
+ * Requires frame_cap even and pcm_stride >= the longest row. */
+int64_t oasr_logmel_stats_slots(int64_t frame_cap);
+int oasr_logmel_f32(const float* pcm, int64_t pcm_stride, const int32_t* n_samples, int32_t batch,
+                    int64_t frame_cap, const uint32_t* tables, float* logmel, float* stats,
+                    void* stream);
+
+/* Per-utterance, per-mel-bin normalisation over all frames ((v-mean)/sqrt(var_ddof1+1e-7)) and
+ * stacking of frame pairs.  feats: device float32 [B][t_pad][160]; rows >= num_stacked are
+ * zero-filled; lengths: device int32[B] receives num_stacked(n_samples[b]).
+ * Requires 2*t_pad <= frame_cap. */
+int oasr_feature_norm_stack(const float* logmel, float* stats, const int32_t* n_samples,
+                            int32_t batch, int64_t frame_cap, int64_t t_pad, float* feats,
+                            int32_t* lengths, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Conformer encoder.  NOT IN THE REFERENCE (the remote model call of
+ * ref gemini_pipeline.py:512-530 occupies this slot).  Weights are caller-owned device buffers
+ * that must outlive the handle. */
+typedef struct oasr_encoder_config {
+    int32_t feat_dim;     /* 160 */
+    int32_t d_model;      /* multiple of 256 */
+    int32_t ffn_dim;      /* multiple of 256 */
+    int32_t n_heads;      /* d_model / n_heads must be 64 */
+    int32_t n_layers;
+    int32_t conv_kernel;  /* 31 */
+    int32_t left_max;     /* 64 */
+    int32_t right_max;    /* 8 */
+    float ln_eps;
+} oasr_encoder_config;
+
+/* bf16 matrices are row-major [out][in] (the layout of a Linear weight); vectors are float32. */
+typedef struct oasr_layer_weights {
+    const float *ffn1_ln_w, *ffn1_ln_b;
+    const uint16_t* ffn1_w1; const float* ffn1_b1;   /* [ffn][d] */
+    const uint16_t* ffn1_w2; const float* ffn1_b2;   /* [d][ffn] */
+    const float *attn_ln_w, *attn_ln_b;
+    const uint16_t* wqkv; const float* bqkv;         /* [3d][d]: q rows, then k rows, then v rows */
+    const uint16_t* wo; const float* bo;             /* [d][d] */
+    const uint16_t* dist_emb;                        /* [96][64] bf16, rows >= left+right+1 zero */
+    const float *conv_ln_w, *conv_ln_b;
+    const uint16_t* pw1;   /* [2d][d], GLU-interleaved: row 32*g+i (i<16) = value row 16*g+i,
+                              row 32*g+16+i = gate row d+16*g+i */
+    const float* dw;       /* [conv_kernel][d] float32 (tap-major) */
+    const float *dw_ln_w, *dw_ln_b;
+    const uint16_t* pw2;   /* [d][d] */
+    const float *ffn2_ln_w, *ffn2_ln_b;
+    const uint16_t* ffn2_w1; const float* ffn2_b1;
+    const uint16_t* ffn2_w2; const float* ffn2_b2;
+    const float *final_ln_w, *final_ln_b;
+} oasr_layer_weights;
+
+typedef struct oasr_top_weights {
+    const float *fp_ln_w, *fp_ln_b;   /* [160] */
+    const uint16_t* fp_w;             /* [d][192] bf16, columns >= 160 zero */
+    const float* fp_b;                /* [d] */
+} oasr_top_weights;
+
+typedef struct oasr_encoder oasr_encoder;
+
+int oasr_encoder_create(const oasr_encoder_config* cfg, const oasr_top_weights* top,
+                        const oasr_layer_weights* layers, oasr_encoder** out);
+void oasr_encoder_destroy(oasr_encoder* enc);
+
+/* Rows of the activation matrices for a batch: round_up(batch * t_pad, 256). */
+int64_t oasr_encoder_rows(int32_t batch, int64_t t_pad);
+/* Bytes of caller-provided device workspace for oasr_encoder_forward. */
+int64_t oasr_encoder_workspace_bytes(const oasr_encoder* enc, int32_t batch, int64_t t_pad);
+
+/* feats    device float32 [B][t_pad][160]  (t_pad multiple of 32)
+ * lengths  device int32[B], valid stacked frames per utterance (keys >= length are masked)
+ * out      device float32 [rows][d_model], rows = oasr_encoder_rows(); row b*t_pad+t is frame t
+ *          of utterance b; rows with t >= lengths[b] are unspecified but finite
+ * workspace device, >= oasr_encoder_workspace_bytes(), 256-byte aligned; must be zero-filled once
+ *          before its first use (later calls may reuse it as is)
+ * n_layers_run: run only the first n blocks (<= cfg.n_layers; 0 = input projection only);
+ *          pass -1 for all. */
+int oasr_encoder_forward(const oasr_encoder* enc, const float* feats, const int32_t* lengths,
+                         int32_t batch, int64_t t_pad, float* out, void* workspace,
+                         int64_t workspace_bytes, int32_t n_layers_run, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Individual operators of the encoder, exported so each can be checked on its own.  None has a
+ * counterpart in the reference. */
+
+/* y[rows][d] = LayerNorm(x[rows][d]) * w + b, optionally followed by Swish.  x float32;
+ * y bf16 when out_bf16 != 0 else float32.  d in {160 (y row stride y_stride), multiples of 256
+ * up to 4096}.  Columns d..y_stride-1 of y are zero-filled. */
+int oasr_layernorm(const float* x, const float* w, const float* b, void* y, int64_t rows,
+                   int32_t d, int64_t y_stride, float eps, int32_t out_bf16, int32_t swish,
+                   void* stream);
+
+/* Fused double LayerNorm at a block boundary: x <- LN(x; w1,b1) in place (float32) and
+ * y(bf16) = LN(x_new; w2,b2). */
+int oasr_layernorm2(float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                    uint16_t* y, int64_t rows, int32_t d, float eps, void* stream);
+
+typedef enum oasr_epilogue {
+    OASR_EPI_BIAS_BF16 = 0,        /* c_bf16 = acc + bias */
+    OASR_EPI_BIAS_SWISH_BF16 = 1,  /* c_bf16 = swish(acc + bias) */
+    OASR_EPI_GLU_BF16 = 2,         /* c_bf16[:, n/2] = value * sigmoid(gate), interleaved weights */
+    OASR_EPI_RESIDUAL_F32 = 3,     /* c_f32 = resid_f32 + alpha * (acc + bias) (may alias resid) */
+    OASR_EPI_BIAS_F32 = 4          /* c_f32 = acc + bias */
+} oasr_epilogue;
+
+/* C[m][n] = epilogue(sum_k A[m][k] * W[n][k]).  A bf16 [m][k], W bf16 [n][k]; m, n multiples of
+ * 256, k a multiple of 64; bias float32[n] or NULL. */
+int oasr_gemm_bf16(const uint16_t* a, const uint16_t* w, const float* bias, const float* resid,
+                   void* c, int64_t m, int64_t n, int64_t k, float alpha, int32_t epilogue,
+                   void* stream);
+
+/* Multi-head self-attention with clamped relative-key bias and key-length masking.
+ * qkv bf16 [rows][3*d] (q | k | v), ctx bf16 [rows][d]; head size 64. */
+int oasr_attention_relkey(const uint16_t* qkv, const uint16_t* dist_emb, const int32_t* lengths,
+                          uint16_t* ctx, int32_t batch, int64_t t_pad, int32_t n_heads,
+                          int32_t left_max, int32_t right_max, void* stream);
+
+/* Causal depthwise convolution over time within each utterance (k-1 zeros on the left):
+ * y[b,t,c] = sum_j w[j][c] * x[b, t-(k-1)+j, c].  x bf16 [rows][d], y float32 [rows][d]. */
+int oasr_dwconv_causal(const uint16_t* x, const float* w, float* y, int32_t batch, int64_t t_pad,
+                       int32_t d, int32_t kernel, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OASR_H */

@@ -1,0 +1,156 @@
+// Conformer encoder forward: the launch sequence over the operators of this library.
+// Host code only — every launch goes to the caller's stream, nothing is allocated or synchronised,
+// so the whole forward can be captured into a hipGraph by the caller.
+#include <new>
+#include <vector>
+
+#include "oasr_common.h"
+
+struct oasr_encoder {
+    oasr_encoder_config cfg;
+    oasr_top_weights top;
+    std::vector<oasr_layer_weights> layers;
+};
+
+namespace oasr {
+
+constexpr int kFeatK = 192;  // 160 feature columns padded to a multiple of the GEMM K-step
+
+struct Workspace {
+    uint16_t* xn;   // [rows][d]      normalised activations (GEMM A operand)
+    uint16_t* big;  // [rows][max(ffn, 3d)]  FFN hidden / fused qkv / padded features
+    uint16_t* ctx;  // [rows][d]      attention context / GLU output
+    float* tmp;     // [rows][d]      depthwise-conv output
+    int64_t bytes;
+};
+
+static Workspace carve(const oasr_encoder_config& c, int64_t rows, char* base) {
+    Workspace w;
+    const int64_t wide = c.ffn_dim > 3 * c.d_model ? c.ffn_dim : 3 * c.d_model;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) {
+        char* p = base ? base + off : nullptr;
+        off += round_up(bytes, 256);
+        return p;
+    };
+    w.xn = reinterpret_cast<uint16_t*>(take(rows * c.d_model * 2));
+    w.big = reinterpret_cast<uint16_t*>(take(rows * wide * 2));
+    w.ctx = reinterpret_cast<uint16_t*>(take(rows * c.d_model * 2));
+    w.tmp = reinterpret_cast<float*>(take(rows * c.d_model * 4));
+    w.bytes = off;
+    return w;
+}
+
+}  // namespace oasr
+
+using namespace oasr;
+
+#define OASR_TRY(call)            \
+    do {                          \
+        int rc_ = (call);         \
+        if (rc_ != OASR_OK) return rc_; \
+    } while (0)
+
+extern "C" {
+
+int oasr_encoder_create(const oasr_encoder_config* cfg, const oasr_top_weights* top,
+                        const oasr_layer_weights* layers, oasr_encoder** out) {
+    OASR_REQUIRE(cfg && top && out, "encoder_create: null pointer");
+    OASR_REQUIRE(cfg->n_layers >= 0 && (cfg->n_layers == 0 || layers), "encoder_create: layers missing");
+    OASR_REQUIRE(cfg->feat_dim == OASR_FEAT_DIM, "encoder_create: feat_dim must be %d", OASR_FEAT_DIM);
+    OASR_REQUIRE(cfg->d_model > 0 && cfg->d_model % 512 == 0 && cfg->d_model <= 4096,
+                 "encoder_create: d_model must be a multiple of 512, at most 4096");
+    OASR_REQUIRE(cfg->ffn_dim > 0 && cfg->ffn_dim % 256 == 0, "encoder_create: ffn_dim must be a multiple of 256");
+    OASR_REQUIRE(cfg->n_heads > 0 && cfg->d_model == cfg->n_heads * 64, "encoder_create: head size must be 64");
+    OASR_REQUIRE(cfg->conv_kernel == 31 || cfg->conv_kernel == 15 || cfg->conv_kernel == 7 || cfg->conv_kernel == 3,
+                 "encoder_create: conv_kernel must be 3, 7, 15 or 31");
+    OASR_REQUIRE(cfg->left_max >= 0 && cfg->right_max >= 0 && cfg->left_max + cfg->right_max + 1 <= 96,
+                 "encoder_create: relative-position window too wide");
+    oasr_encoder* e = new (std::nothrow) oasr_encoder;
+    if (!e) {
+        set_error("encoder_create: out of host memory");
+        return OASR_ENOMEM;
+    }
+    e->cfg = *cfg;
+    e->top = *top;
+    e->layers.assign(layers, layers + cfg->n_layers);
+    *out = e;
+    return OASR_OK;
+}
+
+void oasr_encoder_destroy(oasr_encoder* enc) { delete enc; }
+
+int64_t oasr_encoder_rows(int32_t batch, int64_t t_pad) { return round_up((int64_t)batch * t_pad, 256); }
+
+int64_t oasr_encoder_workspace_bytes(const oasr_encoder* enc, int32_t batch, int64_t t_pad) {
+    if (!enc || batch <= 0 || t_pad <= 0) return 0;
+    return carve(enc->cfg, oasr_encoder_rows(batch, t_pad), nullptr).bytes;
+}
+
+int oasr_encoder_forward(const oasr_encoder* enc, const float* feats, const int32_t* lengths,
+                         int32_t batch, int64_t t_pad, float* out, void* workspace,
+                         int64_t workspace_bytes, int32_t n_layers_run, void* stream) {
+    OASR_REQUIRE(enc && feats && lengths && out && workspace, "encoder_forward: null pointer");
+    OASR_REQUIRE(batch > 0 && t_pad > 0 && t_pad % 32 == 0, "encoder_forward: t_pad must be a multiple of 32");
+    OASR_REQUIRE(((uintptr_t)workspace & 255) == 0, "encoder_forward: workspace must be 256-byte aligned");
+    const oasr_encoder_config& c = enc->cfg;
+    const int64_t rows = oasr_encoder_rows(batch, t_pad);
+    const int64_t live = (int64_t)batch * t_pad;
+    Workspace ws = carve(c, rows, reinterpret_cast<char*>(workspace));
+    if (ws.bytes > workspace_bytes) {
+        set_error("encoder_forward: workspace needs %lld bytes, got %lld", (long long)ws.bytes,
+                  (long long)workspace_bytes);
+        return OASR_ECAPACITY;
+    }
+    int nl = n_layers_run < 0 ? c.n_layers : n_layers_run;
+    OASR_REQUIRE(nl <= c.n_layers, "encoder_forward: n_layers_run exceeds the model depth");
+    const int d = c.d_model, f = c.ffn_dim;
+    float* x = out;  // the residual stream lives in the output buffer
+
+    // input projection: LayerNorm(160) -> bf16 [rows][192] -> Linear -> x
+    OASR_TRY(oasr_layernorm(feats, enc->top.fp_ln_w, enc->top.fp_ln_b, ws.big, live, OASR_FEAT_DIM, kFeatK,
+                            c.ln_eps, 1, 0, stream));
+    OASR_TRY(oasr_gemm_bf16(ws.big, enc->top.fp_w, enc->top.fp_b, nullptr, x, rows, d, kFeatK, 1.0f,
+                            OASR_EPI_BIAS_F32, stream));
+    for (int l = 0; l < nl; ++l) {
+        const oasr_layer_weights& w = enc->layers[l];
+        if (l == 0)
+            OASR_TRY(oasr_layernorm(x, w.ffn1_ln_w, w.ffn1_ln_b, ws.xn, rows, d, d, c.ln_eps, 1, 0, stream));
+        // half-step feed-forward 1
+        OASR_TRY(oasr_gemm_bf16(ws.xn, w.ffn1_w1, w.ffn1_b1, nullptr, ws.big, rows, f, d, 1.0f,
+                                OASR_EPI_BIAS_SWISH_BF16, stream));
+        OASR_TRY(oasr_gemm_bf16(ws.big, w.ffn1_w2, w.ffn1_b2, x, x, rows, d, f, 0.5f,
+                                OASR_EPI_RESIDUAL_F32, stream));
+        // self-attention
+        OASR_TRY(oasr_layernorm(x, w.attn_ln_w, w.attn_ln_b, ws.xn, rows, d, d, c.ln_eps, 1, 0, stream));
+        OASR_TRY(oasr_gemm_bf16(ws.xn, w.wqkv, w.bqkv, nullptr, ws.big, rows, 3 * (int64_t)d, d, 1.0f,
+                                OASR_EPI_BIAS_BF16, stream));
+        OASR_TRY(oasr_attention_relkey(ws.big, w.dist_emb, lengths, ws.ctx, batch, t_pad, c.n_heads,
+                                       c.left_max, c.right_max, stream));
+        OASR_TRY(oasr_gemm_bf16(ws.ctx, w.wo, w.bo, x, x, rows, d, d, 1.0f, OASR_EPI_RESIDUAL_F32, stream));
+        // convolution module
+        OASR_TRY(oasr_layernorm(x, w.conv_ln_w, w.conv_ln_b, ws.xn, rows, d, d, c.ln_eps, 1, 0, stream));
+        OASR_TRY(oasr_gemm_bf16(ws.xn, w.pw1, nullptr, nullptr, ws.ctx, rows, 2 * (int64_t)d, d, 1.0f,
+                                OASR_EPI_GLU_BF16, stream));
+        OASR_TRY(oasr_dwconv_causal(ws.ctx, w.dw, ws.tmp, batch, t_pad, d, c.conv_kernel, stream));
+        OASR_TRY(oasr_layernorm(ws.tmp, w.dw_ln_w, w.dw_ln_b, ws.xn, live, d, d, c.ln_eps, 1, 1, stream));
+        OASR_TRY(oasr_gemm_bf16(ws.xn, w.pw2, nullptr, x, x, rows, d, d, 1.0f, OASR_EPI_RESIDUAL_F32, stream));
+        // half-step feed-forward 2
+        OASR_TRY(oasr_layernorm(x, w.ffn2_ln_w, w.ffn2_ln_b, ws.xn, rows, d, d, c.ln_eps, 1, 0, stream));
+        OASR_TRY(oasr_gemm_bf16(ws.xn, w.ffn2_w1, w.ffn2_b1, nullptr, ws.big, rows, f, d, 1.0f,
+                                OASR_EPI_BIAS_SWISH_BF16, stream));
+        OASR_TRY(oasr_gemm_bf16(ws.big, w.ffn2_w2, w.ffn2_b2, x, x, rows, d, f, 0.5f,
+                                OASR_EPI_RESIDUAL_F32, stream));
+        // block output LayerNorm, fused with the next block's first LayerNorm when there is one
+        if (l + 1 < nl) {
+            const oasr_layer_weights& nx = enc->layers[l + 1];
+            OASR_TRY(oasr_layernorm2(x, w.final_ln_w, w.final_ln_b, nx.ffn1_ln_w, nx.ffn1_ln_b, ws.xn, rows, d,
+                                     c.ln_eps, stream));
+        } else {
+            OASR_TRY(oasr_layernorm(x, w.final_ln_w, w.final_ln_b, x, rows, d, d, c.ln_eps, 0, 0, stream));
+        }
+    }
+    return OASR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+// Shared host/device helpers for liboasr_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "oasr.h"
+
+namespace oasr {
+
+void set_error(const char* fmt, ...);
+
+#define OASR_REQUIRE(cond, ...)                                  \
+    do {                                                         \
+        if (!(cond)) {                                           \
+            ::oasr::set_error(__VA_ARGS__);                      \
+            return OASR_EINVAL;                                  \
+        }                                                        \
+    } while (0)
+
+#define OASR_CHECK_LAUNCH(what)                                                         \
+    do {                                                                                \
+        hipError_t e_ = hipGetLastError();                                              \
+        if (e_ != hipSuccess) {                                                         \
+            ::oasr::set_error("%s: launch failed: %s", what, hipGetErrorString(e_));    \
+            return OASR_EHIP;                                                           \
+        }                                                                               \
+    } while (0)
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = one MFMA A/B fragment
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// float -> bf16, round to nearest even.  Inputs on this path are finite (LayerNorm keeps the
+// activations bounded), so the integer form is safe and cheap.
+__device__ __forceinline__ uint16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float swishf(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+}  // namespace oasr

@@ -1,0 +1,165 @@
+"""Device engine: PCM batches -> log-mel features -> conformer encoder states on one MI355X.
+
+Fills the slot the reference gives to its remote model call
+(ref:src/omnilingual_asr/models/inference/gemini_pipeline.py:474-539).  All device arithmetic is in
+liboasr_hip.so; torch only owns the memory and the stream.  One engine belongs to one device and is
+not re-entrant: callers serialise `encode_batch` (the pipeline holds a lock).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _hip
+from .weights import Geometry, init_random_weights, pack_for_device, resolve_geometry
+
+SAMPLE_RATE = 16000
+
+
+def pad_frames(t: int) -> int:
+    """Stacked-frame pitch per utterance: multiple of 32 (attention / convolution tiling)."""
+    return max(32, (int(t) + 31) // 32 * 32)
+
+
+class HipEngine:
+    def __init__(self, model="G300", *, weights: dict | None = None, seed: int = 0,
+                 device: int | str | torch.device | None = None, use_graphs: bool = True):
+        _hip.lib()
+        _hip.require_device()
+        self.geometry: Geometry = resolve_geometry(model)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None \
+            else torch.device(device)
+        if self.device.type != "cuda":
+            raise _hip.OasrError("HipEngine needs a HIP device; there is no CPU fallback")
+        g = self.geometry
+        if weights is None:
+            weights = init_random_weights(g, seed)
+        self._packed = pack_for_device(weights, g, self.device)   # keeps device buffers alive
+        self._tables = torch.from_numpy(_hip.logmel_table_blob().view(np.int32)).to(self.device)
+        self._handle = self._create_handle()
+        self._buffers: dict = {}
+        self._graphs: dict = {}
+        self.use_graphs = use_graphs
+
+    # ---- set-up ---------------------------------------------------------------------------------------
+    def _create_handle(self):
+        g = self.geometry
+        cfg = _hip.EncoderConfig(g.feat_dim, g.d_model, g.ffn_dim, g.n_heads, g.n_layers,
+                                 g.conv_kernel, g.left_max, g.right_max, g.ln_eps)
+        top = _hip.TopWeights(**{k: self._packed["top"][k].data_ptr() for k in _hip.TOP_FIELDS})
+        arr = (_hip.LayerWeights * max(1, g.n_layers))()
+        for i, L in enumerate(self._packed["layers"]):
+            for k in _hip.LAYER_FIELDS:
+                setattr(arr[i], k, L[k].data_ptr())
+        handle = C.c_void_p()
+        _hip.check(_hip.lib().oasr_encoder_create(C.byref(cfg), C.byref(top), arr, C.byref(handle)),
+                   "oasr_encoder_create")
+        return handle
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            _hip.lib().oasr_encoder_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- buffers --------------------------------------------------------------------------------------
+    def _get_buffers(self, batch: int, n_samples_max: int):
+        frames = _hip.num_frames(n_samples_max)
+        t_pad = pad_frames(frames // 2)
+        frame_cap = 2 * t_pad
+        key = (batch, t_pad)
+        buf = self._buffers.get(key)
+        if buf is None:
+            dev, g = self.device, self.geometry
+            rows = int(_hip.lib().oasr_encoder_rows(batch, t_pad))
+            slots = int(_hip.lib().oasr_logmel_stats_slots(frame_cap))
+            ws_bytes = int(_hip.lib().oasr_encoder_workspace_bytes(self._handle, batch, t_pad))
+            buf = {
+                "t_pad": t_pad, "frame_cap": frame_cap, "rows": rows,
+                "logmel": torch.zeros((batch, frame_cap, 80), dtype=torch.float32, device=dev),
+                "stats": torch.zeros((batch, slots, 80, 2), dtype=torch.float32, device=dev),
+                "feats": torch.zeros((batch, t_pad, 160), dtype=torch.float32, device=dev),
+                "lengths": torch.zeros((batch,), dtype=torch.int32, device=dev),
+                "out": torch.zeros((rows, g.d_model), dtype=torch.float32, device=dev),
+                "workspace": torch.zeros((ws_bytes,), dtype=torch.uint8, device=dev),
+                "ws_bytes": ws_bytes,
+            }
+            self._buffers[key] = buf
+        return buf
+
+    # ---- stages ---------------------------------------------------------------------------------------
+    def features(self, pcm: torch.Tensor, n_valid: torch.Tensor, buf=None):
+        """pcm float32 [B, N] and n_valid int32 [B] on the device -> (feats [B, t_pad, 160], lengths)."""
+        batch, stride = pcm.shape
+        if buf is None:
+            buf = self._get_buffers(batch, stride)
+        st = _hip.current_stream_ptr()
+        L = _hip.lib()
+        _hip.check(L.oasr_logmel_f32(_hip._ptr(pcm, torch.float32), stride, _hip._ptr(n_valid, torch.int32),
+                                     batch, buf["frame_cap"], self._tables.data_ptr(),
+                                     buf["logmel"].data_ptr(), buf["stats"].data_ptr(), st), "oasr_logmel_f32")
+        _hip.check(L.oasr_feature_norm_stack(buf["logmel"].data_ptr(), buf["stats"].data_ptr(),
+                                             n_valid.data_ptr(), batch, buf["frame_cap"], buf["t_pad"],
+                                             buf["feats"].data_ptr(), buf["lengths"].data_ptr(), st),
+                   "oasr_feature_norm_stack")
+        return buf["feats"], buf["lengths"]
+
+    def encode_features(self, feats: torch.Tensor, lengths: torch.Tensor, n_layers: int = -1, buf=None):
+        """feats float32 [B, t_pad, 160], lengths int32 [B] -> hidden float32 [B, t_pad, d] (a view)."""
+        batch, t_pad, _ = feats.shape
+        if buf is None:
+            buf = self._get_buffers(batch, 160 * (2 * t_pad - 1) + 400)
+        if buf["t_pad"] != t_pad:
+            raise _hip.OasrError("feature pitch does not match the buffer set")
+        _hip.check(_hip.lib().oasr_encoder_forward(
+            self._handle, _hip._ptr(feats, torch.float32), _hip._ptr(lengths, torch.int32), batch, t_pad,
+            buf["out"].data_ptr(), buf["workspace"].data_ptr(), buf["ws_bytes"], n_layers,
+            _hip.current_stream_ptr()), "oasr_encoder_forward")
+        g = self.geometry
+        return buf["out"][: batch * t_pad].view(batch, t_pad, g.d_model)
+
+    def step(self, pcm: torch.Tensor, n_valid: torch.Tensor):
+        """One pass of the whole device path over one resident batch (eager launches)."""
+        buf = self._get_buffers(pcm.shape[0], pcm.shape[1])
+        feats, lengths = self.features(pcm, n_valid, buf)
+        return self.encode_features(feats, lengths, -1, buf), lengths
+
+    def step_graph(self, pcm: torch.Tensor, n_valid: torch.Tensor):
+        """Same as `step`, replayed from a HIP graph captured on first use for this (pcm buffer,
+        shape): the ~200 launches of a forward become one graph launch."""
+        key = (pcm.data_ptr(), n_valid.data_ptr(), tuple(pcm.shape))
+        entry = self._graphs.get(key)
+        if entry is None:
+            self.step(pcm, n_valid)                  # warm-up: allocates buffers outside capture
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                hidden, lengths = self.step(pcm, n_valid)
+            entry = (graph, hidden, lengths)
+            self._graphs[key] = entry
+        graph, hidden, lengths = entry
+        graph.replay()
+        return hidden, lengths
+
+    # ---- host-facing convenience ----------------------------------------------------------------------
+    def encode_batch(self, pcm, n_valid):
+        """pcm: float32 [B, N] numpy array or tensor (host or device); n_valid: valid samples per row.
+        Returns (hidden [B, t_pad, d] float32 device tensor, lengths numpy int32 [B])."""
+        pcm_t = torch.as_tensor(pcm, dtype=torch.float32)
+        if pcm_t.dim() != 2:
+            raise ValueError("pcm must be [batch, samples]")
+        if pcm_t.shape[1] % 4:
+            pcm_t = torch.nn.functional.pad(pcm_t, (0, 4 - pcm_t.shape[1] % 4))
+        pcm_d = pcm_t.to(self.device, non_blocking=True).contiguous()
+        nv = torch.as_tensor(np.asarray(n_valid, dtype=np.int32)).to(self.device)
+        with torch.cuda.device(self.device):
+            hidden, lengths = self.step(pcm_d, nv)
+            return hidden, lengths.cpu().numpy()

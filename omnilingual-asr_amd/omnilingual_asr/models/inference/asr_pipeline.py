@@ -1,0 +1,381 @@
+"""Local ASR engine front: duration gate, chunk plan, batched device encode, merge, retry.
+
+Host-side mirror of ref:src/omnilingual_asr/models/inference/gemini_pipeline.py.  Same public
+names, argument meaning, progress protocol and error behaviour; the remote model call
+(ref :512-530) is replaced by an engine object that turns PCM batches into encoder states on the
+GPU (`omnilingual_asr.engine_hip.HipEngine`).  Where the reference fans chunks out to 4 threads of
+network calls (ref :623-641), this module packs them into batches for one device, or shards them
+over the ranks of a `torch.distributed` job (`omnilingual_asr.distributed`).
+"""
+
+from __future__ import annotations
+
+import json
+import re
+import threading
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import Any, Callable, List, Optional, Sequence
+
+import numpy as np
+
+from omnilingual_asr import audio as _audio
+
+SAMPLE_RATE = 16000
+
+# Reference constants (ref gemini_pipeline.py:217-219), kept for callers that import them.
+CHUNK_DURATION_SECONDS = 300
+MIN_DURATION_FOR_CHUNKING = 360
+MAX_PARALLEL_CHUNKS = 4
+
+# Defaults of the local engine: 30 s utterances (the encoder's design length), gate at 30 s.
+DEFAULT_CHUNK_SECONDS = 30.0
+DEFAULT_MIN_CHUNKING_SECONDS = 30.0
+DEFAULT_BATCH = 32
+
+
+@dataclass(frozen=True)
+class WordTimestamp:
+    """ref gemini_pipeline.py:39-45"""
+    word: str
+    start: float
+    end: float
+
+
+@dataclass
+class GeminiTranscriptSegment:
+    """Engine-level segment record; field order and defaults of ref gemini_pipeline.py:48-61."""
+    start: float
+    end: float
+    speaker: str
+    text: str
+    language: Optional[str] = None
+    language_code: Optional[str] = None
+    languages: Optional[List[dict]] = None
+    emotion: Optional[str] = None
+    translation: Optional[str] = None
+    words: Optional[List[WordTimestamp]] = None
+
+
+@dataclass
+class GeminiTranscriptionResult:
+    """ref gemini_pipeline.py:64-70"""
+    summary: Optional[str] = None
+    segments: List[GeminiTranscriptSegment] = field(default_factory=list)
+    detected_languages: Optional[List[dict]] = None
+
+
+TranscriptSegment = GeminiTranscriptSegment
+TranscriptionResult = GeminiTranscriptionResult
+
+_FIELD_SECONDS = {2: (60.0, 1.0), 3: (3600.0, 60.0, 1.0)}
+_MIME_BY_SUFFIX = {".wav": "audio/wav", ".mp3": "audio/mp3", ".aiff": "audio/aiff", ".aac": "audio/aac",
+                   ".ogg": "audio/ogg", ".flac": "audio/flac", ".m4a": "audio/mp4"}
+
+
+def parse_timestamp(timestamp_str: str) -> float:
+    """'MM:SS', 'HH:MM:SS' or raw seconds -> seconds; anything else -> 0.0
+    (behaviour of ref gemini_pipeline.py:73-103)."""
+    if not timestamp_str:
+        return 0.0
+    parts = timestamp_str.strip().split(":")
+    try:
+        weights = _FIELD_SECONDS.get(len(parts))
+        if weights is None:
+            return float(timestamp_str)
+        total = 0.0
+        for i, (txt, w) in enumerate(zip(parts, weights)):
+            total = total + (float(txt) if i == len(parts) - 1 else int(txt)) * w
+        return total
+    except ValueError:
+        return 0.0
+
+
+def get_mime_type(file_path: Path) -> str:
+    """ref gemini_pipeline.py:106-118"""
+    return _MIME_BY_SUFFIX.get(Path(file_path).suffix.lower(), "audio/wav")
+
+
+def get_audio_duration(audio_path: Path) -> float:
+    """Duration in seconds from the file header; 0.0 on any failure, as the reference's ffprobe
+    wrapper does (ref gemini_pipeline.py:222-240)."""
+    try:
+        return float(_audio.wav_duration(audio_path))
+    except Exception:
+        return 0.0
+
+
+def plan_chunks(total_samples: int, chunk_seconds: float = DEFAULT_CHUNK_SECONDS,
+                min_chunking_seconds: float = DEFAULT_MIN_CHUNKING_SECONDS,
+                sample_rate: int = SAMPLE_RATE) -> np.ndarray:
+    """Integer chunk plan [n, 2] (start_sample, end_sample) computed by liboasr_hip.so
+    (`oasr_plan_chunks`): the reference's fixed-length plan (ref :256-310) behind its strict
+    duration gate (ref :713-714)."""
+    from omnilingual_asr import _hip
+    return _hip.plan_chunks(total_samples, sample_rate, chunk_seconds, min_chunking_seconds)
+
+
+def split_audio_into_chunks(audio_path: Path, chunk_duration: float = CHUNK_DURATION_SECONDS,
+                            output_dir: Optional[Path] = None) -> List[tuple]:
+    """Same contract as ref gemini_pipeline.py:243-310 — a list of (chunk_path, start_offset) with
+    chunk files `chunk_0000<ext>` of `chunk_duration` seconds written to `output_dir` — but the
+    slices are cut from the decoded PCM and written as 16-bit WAV instead of by ffmpeg.  A file
+    whose duration cannot be determined is returned whole."""
+    import tempfile
+    import wave
+
+    audio_path = Path(audio_path)
+    if output_dir is None:
+        output_dir = Path(tempfile.mkdtemp(prefix="audio_chunks_"))
+    total = get_audio_duration(audio_path)
+    if total <= 0:
+        return [(audio_path, 0.0)]
+    ext = audio_path.suffix or ".wav"
+    try:
+        pcm, rate = _audio.read_wav(audio_path)
+    except Exception:
+        return [(audio_path, 0.0)]
+    out, start, idx = [], 0.0, 0
+    while start < total:
+        lo = int(round(start * rate))
+        hi = min(int(round((start + chunk_duration) * rate)), pcm.shape[0])
+        path = Path(output_dir) / f"chunk_{idx:04d}{ext}"
+        try:
+            with wave.open(str(path), "wb") as w:
+                w.setnchannels(pcm.shape[1])
+                w.setsampwidth(2)
+                w.setframerate(rate)
+                w.writeframes((np.clip(pcm[lo:hi], -1.0, 32767.0 / 32768.0) * 32768.0).astype("<i2").tobytes())
+            out.append((path, start))
+        except Exception:
+            pass
+        start += chunk_duration
+        idx += 1
+    return out if out else [(audio_path, 0.0)]
+
+
+def parse_response(response_text: str) -> GeminiTranscriptionResult:
+    """JSON transcript -> records, with the reference's defaults and fix-ups
+    (ref gemini_pipeline.py:364-453): fenced ```json blocks accepted, `end <= start` becomes
+    `start + 1.0`, speaker defaults to 'Speaker 1', emotion to 'neutral', languages unioned by
+    code in first-seen order.  Kept so transcripts produced elsewhere can be ingested."""
+    try:
+        data = json.loads(response_text)
+    except json.JSONDecodeError:
+        m = re.search(r"```json\s*(.*?)\s*```", response_text, re.DOTALL)
+        if m is None:
+            return GeminiTranscriptionResult(summary="Failed to parse transcription", segments=[])
+        data = json.loads(m.group(1))
+    segments, langs, seen = [], [], set()
+    for item in data.get("segments", []):
+        t0 = parse_timestamp(item.get("timestamp_start", "0:00"))
+        t1 = parse_timestamp(item.get("timestamp_end", "0:00"))
+        if t1 <= t0:
+            t1 = t0 + 1.0
+        listed = item.get("languages", [])
+        if listed:
+            name, code = listed[0].get("name"), listed[0].get("code")
+            per_seg = [{"name": x.get("name", ""), "code": x.get("code", "")} for x in listed]
+            pairs = [(x.get("code", ""), x.get("name", x.get("code", ""))) for x in listed]
+        else:
+            name, code, per_seg = item.get("language"), item.get("language_code"), None
+            pairs = [(code, name or code)] if code else []
+        for c, n in pairs:
+            if c and c not in seen:
+                seen.add(c)
+                langs.append({"code": c, "language": n})
+        segments.append(GeminiTranscriptSegment(
+            start=t0, end=t1, speaker=item.get("speaker", "Speaker 1"), text=item.get("content", ""),
+            language=name, language_code=code, languages=per_seg,
+            emotion=item.get("emotion", "neutral"), translation=item.get("translation"), words=None))
+    summary = data.get("summary", "")
+    return GeminiTranscriptionResult(summary=summary or None, segments=segments,
+                                     detected_languages=langs or None)
+
+
+def offset_result(result: GeminiTranscriptionResult, start_offset: float) -> GeminiTranscriptionResult:
+    """Shift a chunk's segments by the chunk start (ref gemini_pipeline.py:555-575).  As in the
+    reference the per-segment `languages` list is not carried over."""
+    shifted = [GeminiTranscriptSegment(
+        start=s.start + start_offset, end=s.end + start_offset, speaker=s.speaker, text=s.text,
+        language=s.language, language_code=s.language_code, emotion=s.emotion,
+        translation=s.translation, words=s.words) for s in result.segments]
+    return GeminiTranscriptionResult(summary=result.summary, segments=shifted,
+                                     detected_languages=result.detected_languages)
+
+
+def merge_results(results: Sequence[GeminiTranscriptionResult]) -> GeminiTranscriptionResult:
+    """Merge per-chunk results (ref gemini_pipeline.py:646-678): stable sort by first-segment start
+    (chunks without segments last), concatenate, union languages by code, join summaries."""
+    ordered = sorted(results, key=lambda r: r.segments[0].start if r.segments else float("inf"))
+    merged: List[GeminiTranscriptSegment] = []
+    langs: List[dict] = []
+    seen = set()
+    for r in ordered:
+        merged.extend(r.segments)
+        for lang in r.detected_languages or []:
+            code = lang.get("code", "")
+            if code and code not in seen:
+                seen.add(code)
+                langs.append(lang)
+    summaries = [r.summary for r in ordered if r.summary]
+    return GeminiTranscriptionResult(summary=" ".join(summaries) if summaries else None,
+                                     segments=merged, detected_languages=langs or None)
+
+
+@dataclass
+class ChunkRecord:
+    """What the device path reports per chunk (also the unit gathered across ranks)."""
+    chunk_idx: int
+    start_sample: int
+    end_sample: int
+    n_frames: int          # valid encoder frames (40 ms each)
+    activity: float        # mean |encoder state| over the valid frames
+
+    def to_result(self, sample_rate: int = SAMPLE_RATE) -> GeminiTranscriptionResult:
+        """Chunk-local result: one segment spanning the chunk.  No decoder head exists yet, so `text`
+        is empty; speaker and emotion take the reference's defaults (ref :435, :440)."""
+        dur = (self.end_sample - self.start_sample) / float(sample_rate)
+        end = dur if dur > 0.0 else 1.0          # the reference's end<=start fix-up (ref :396-397)
+        seg = GeminiTranscriptSegment(start=0.0, end=end, speaker="Speaker 1", text="",
+                                      emotion="neutral", words=None)
+        return GeminiTranscriptionResult(summary=None, segments=[seg], detected_languages=None)
+
+
+class GeminiASRPipeline:
+    """Drop-in for the reference's engine class (ref gemini_pipeline.py:313-741) running locally.
+
+    `api_key` is accepted and ignored (the reference raises without one, ref :329-334; a local
+    engine needs none).  `model` names an encoder geometry ("G300", "G7B"); the reference's remote
+    model names select the default.  `engine` may be injected (anything with
+    `encode_batch(pcm[B,N], n_valid) -> (hidden[B,T,d], lengths)`); by default a `HipEngine` is
+    created on first use and its absence (no library, no GPU) is an error."""
+
+    def __init__(self, api_key: Optional[str] = None, model: str = "gemini-3-flash-preview", *,
+                 engine: Any = None, device: Any = None, chunk_seconds: float = DEFAULT_CHUNK_SECONDS,
+                 min_chunking_seconds: float = DEFAULT_MIN_CHUNKING_SECONDS,
+                 batch_size: int = DEFAULT_BATCH, seed: int = 0, process_group: Any = None) -> None:
+        self.api_key = api_key
+        self.model = model
+        self.chunk_seconds = float(chunk_seconds)
+        self.min_chunking_seconds = float(min_chunking_seconds)
+        self.batch_size = int(batch_size)
+        self.process_group = process_group
+        self._device = device
+        self._seed = seed
+        self._engine = engine
+        self._engine_lock = threading.Lock()   # one device stream: concurrent callers serialise here
+
+    # ---- engine ---------------------------------------------------------------------------------------
+    @property
+    def engine(self):
+        if self._engine is None:
+            from omnilingual_asr.engine_hip import HipEngine
+            self._engine = HipEngine(self.model, seed=self._seed, device=self._device)
+        return self._engine
+
+    def _encode_chunks(self, pcm: np.ndarray, bounds: np.ndarray, first_idx: int = 0) -> List[ChunkRecord]:
+        """Run the chunks `bounds[i] = (start, end)` of `pcm` through the engine in batches."""
+        records: List[ChunkRecord] = []
+        n = len(bounds)
+        for lo in range(0, n, self.batch_size):
+            part = bounds[lo: lo + self.batch_size]
+            width = int(max(e - s for s, e in part))
+            width = max(width, 400)
+            batch = np.zeros((len(part), width), dtype=np.float32)
+            for i, (s, e) in enumerate(part):
+                batch[i, : e - s] = pcm[s:e]
+            n_valid = [int(e - s) for s, e in part]
+            try:
+                with self._engine_lock:
+                    hidden, lengths = self.engine.encode_batch(batch, n_valid)
+                    acts = _mean_abs(hidden, lengths)
+            except Exception as exc:  # per-batch failure is tolerated, as per-chunk failure is in
+                print(f"Chunk transcription failed: {exc}")   # the reference (ref :635-641)
+                continue
+            for i, (s, e) in enumerate(part):
+                records.append(ChunkRecord(first_idx + lo + i, int(s), int(e), int(lengths[i]), float(acts[i])))
+        return records
+
+    # ---- single-utterance path (ref :474-539) -----------------------------------------------------------
+    def transcribe(self, audio_path, *, progress_callback: Optional[Callable[[str, int], None]] = None,
+                   language: Optional[str] = None, speaker_count: Optional[str] = None,
+                   ) -> GeminiTranscriptionResult:
+        def report(step, idx):
+            if progress_callback:
+                progress_callback(step, idx)
+
+        report("uploading", 0)
+        pcm = _audio.load_audio_16k(Path(audio_path))
+        report("transcribing", 1)
+        bounds = np.array([[0, pcm.shape[0]]], dtype=np.int64)
+        with_state = self._encode_chunks(pcm, bounds)
+        if not with_state:
+            raise RuntimeError("encoder produced no output for " + str(audio_path))
+        report("processing", 2)
+        result = with_state[0].to_result()
+        report("done", 3)
+        return result
+
+    def _transcribe_chunk(self, record: ChunkRecord) -> GeminiTranscriptionResult:
+        """Chunk-local result shifted to file time (ref :541-575)."""
+        return offset_result(record.to_result(), record.start_sample / float(SAMPLE_RATE))
+
+    # ---- long-audio path (ref :577-682) -----------------------------------------------------------------
+    def transcribe_chunked(self, audio_path, *, progress_callback: Optional[Callable[[str, int], None]] = None,
+                           language: Optional[str] = None, speaker_count: Optional[str] = None,
+                           ) -> GeminiTranscriptionResult:
+        def report(step, idx):
+            if progress_callback:
+                progress_callback(step, idx)
+
+        report("uploading", 0)
+        pcm = _audio.load_audio_16k(Path(audio_path))
+        bounds = plan_chunks(pcm.shape[0], self.chunk_seconds, self.min_chunking_seconds)
+        if len(bounds) <= 1:
+            # same fall-through as the reference (ref :609-616), including its repeated progress steps
+            return self.transcribe(audio_path, progress_callback=progress_callback,
+                                   language=language, speaker_count=speaker_count)
+        report("transcribing", 1)
+        if self.process_group is not None:
+            from omnilingual_asr import distributed as _dist
+            records = _dist.encode_sharded(self, pcm, bounds, self.process_group)
+        else:
+            records = self._encode_chunks(pcm, bounds)
+        report("processing", 2)
+        merged = merge_results([self._transcribe_chunk(r) for r in records])
+        report("done", 3)
+        return merged
+
+    # ---- gate + retry (ref :684-741) ----------------------------------------------------------------------
+    def transcribe_with_retry(self, audio_path, *, max_retries: int = 3,
+                              progress_callback: Optional[Callable[[str, int], None]] = None,
+                              language: Optional[str] = None, speaker_count: Optional[str] = None,
+                              ) -> GeminiTranscriptionResult:
+        import time
+
+        audio_path = Path(audio_path)
+        use_chunking = get_audio_duration(audio_path) > self.min_chunking_seconds
+        run = self.transcribe_chunked if use_chunking else self.transcribe
+        last_error = None
+        for attempt in range(max_retries):
+            try:
+                return run(audio_path, progress_callback=progress_callback, language=language,
+                           speaker_count=speaker_count)
+            except Exception as exc:
+                last_error = exc
+                if attempt < max_retries - 1:
+                    time.sleep(2 ** attempt)
+        raise RuntimeError(f"Failed to transcribe after {max_retries} attempts: {last_error}")
+
+
+ASRPipeline = GeminiASRPipeline
+
+
+def _mean_abs(hidden, lengths) -> List[float]:
+    """Mean |state| over each utterance's valid frames (one small device reduction per batch)."""
+    out = []
+    for i, n in enumerate(lengths):
+        n = int(n)
+        out.append(float(hidden[i, :n].abs().mean()) if n > 0 else 0.0)
+    return out

@@ -1,0 +1,139 @@
+"""Oracle for the conformer encoder forward.  TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+PARITY UNPINNED against the reference: ref:src/omnilingual_asr contains no encoder and no
+weights.  The block structure below is declared by this build; it mirrors the third-party
+stand-in tf:models/wav2vec2_bert/modeling_wav2vec2_bert.py:119-131 (feature projection),
+:134-154 (feed-forward), :157-226 (convolution module), :263-337 (relative-key attention),
+:398-461 (block) with that model's default hyper-parameters, against which
+`tests/golden/standin_encoder.npz` cross-checks it.
+
+Plain PyTorch on the CPU in float32 (or float64 when asked); eval mode, no dropout.
+
+Encoder input  : feats [B, T, 160], lengths [B] (valid stacked frames per utterance)
+  h = Linear_160->d(LayerNorm_160(feats))
+  per block:
+    h = h + 0.5 * FFN1(LN(h))                 FFN = Linear d->f, Swish, Linear f->d
+    h = h + MHSA(LN(h))                       H heads of d/H, scores (q.k + q.E[clip(j-i,-L,R)+L]) / sqrt(dh),
+                                              keys j >= length masked, softmax, P.V, Linear d->d
+    h = h + Conv(LN(h))                       pointwise d->2d (no bias), GLU, causal depthwise k=31
+                                              (30 zeros on the left), LN, Swish, pointwise d->d (no bias)
+    h = h + 0.5 * FFN2(LN(h))
+    h = LN_final(h)
+Rows t >= lengths[b] of the output are unspecified (valid rows never depend on them: the
+convolution is causal and masked keys get zero weight).
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+import torch.nn.functional as F
+
+
+@dataclass(frozen=True)
+class Geometry:
+    name: str = "G300"
+    feat_dim: int = 160
+    d_model: int = 1024
+    ffn_dim: int = 4096
+    n_heads: int = 16
+    n_layers: int = 12
+    conv_kernel: int = 31
+    left_max: int = 64
+    right_max: int = 8
+    ln_eps: float = 1e-5
+
+    @property
+    def head_dim(self) -> int:
+        return self.d_model // self.n_heads
+
+    @property
+    def n_dist(self) -> int:
+        return self.left_max + self.right_max + 1
+
+
+G300 = Geometry()
+G7B = Geometry(name="G7B", d_model=4096, ffn_dim=16384, n_heads=32, n_layers=18)
+
+LAYER_KEYS = (
+    "ffn1_ln_w", "ffn1_ln_b", "ffn1_w1", "ffn1_b1", "ffn1_w2", "ffn1_b2",
+    "attn_ln_w", "attn_ln_b", "wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo", "dist_emb",
+    "conv_ln_w", "conv_ln_b", "pw1", "dw", "dw_ln_w", "dw_ln_b", "pw2",
+    "ffn2_ln_w", "ffn2_ln_b", "ffn2_w1", "ffn2_b1", "ffn2_w2", "ffn2_b2",
+    "final_ln_w", "final_ln_b",
+)
+
+
+def _swish(x):
+    return x * torch.sigmoid(x)
+
+
+def _ffn(x, w, pfx):
+    return F.linear(_swish(F.linear(x, w[pfx + "_w1"], w[pfx + "_b1"])), w[pfx + "_w2"], w[pfx + "_b2"])
+
+
+def attention(x, lengths, w, g: Geometry):
+    b, t, d = x.shape
+    h, dh = g.n_heads, g.head_dim
+    q = F.linear(x, w["wq"], w["bq"]).view(b, t, h, dh).transpose(1, 2)
+    k = F.linear(x, w["wk"], w["bk"]).view(b, t, h, dh).transpose(1, 2)
+    v = F.linear(x, w["wv"], w["bv"]).view(b, t, h, dh).transpose(1, 2)
+    scale = 1.0 / math.sqrt(dh)
+    scores = torch.matmul(q, k.transpose(-1, -2)) * scale
+    pos = torch.arange(t)
+    dist = (pos[None, :] - pos[:, None]).clamp(-g.left_max, g.right_max) + g.left_max   # [i, j]
+    qe = torch.matmul(q, w["dist_emb"].t())                   # [b, h, t, n_dist]
+    bias = torch.gather(qe, 3, dist[None, None].expand(b, h, t, t))
+    scores = scores + bias * scale
+    key_ok = pos[None, :] < lengths[:, None].to(torch.long)   # [b, j]
+    scores = scores.masked_fill(~key_ok[:, None, None, :], float("-inf"))
+    p = torch.softmax(scores, dim=-1)
+    ctx = torch.matmul(p, v).transpose(1, 2).reshape(b, t, d)
+    return F.linear(ctx, w["wo"], w["bo"])
+
+
+def conv_module(x, w, g: Geometry):
+    d = g.d_model
+    y = F.layer_norm(x, (d,), w["conv_ln_w"], w["conv_ln_b"], g.ln_eps)
+    y = F.linear(y, w["pw1"])
+    y = y[..., :d] * torch.sigmoid(y[..., d:])               # GLU over the channel dim
+    yt = F.pad(y.transpose(1, 2), (g.conv_kernel - 1, 0))
+    yt = F.conv1d(yt, w["dw"][:, None, :], groups=d)
+    y = F.layer_norm(yt.transpose(1, 2), (d,), w["dw_ln_w"], w["dw_ln_b"], g.ln_eps)
+    return F.linear(_swish(y), w["pw2"])
+
+
+def block(x, lengths, w, g: Geometry, taps=None):
+    d = g.d_model
+    x = x + 0.5 * _ffn(F.layer_norm(x, (d,), w["ffn1_ln_w"], w["ffn1_ln_b"], g.ln_eps), w, "ffn1")
+    if taps is not None:
+        taps["ffn1"] = x
+    x = x + attention(F.layer_norm(x, (d,), w["attn_ln_w"], w["attn_ln_b"], g.ln_eps), lengths, w, g)
+    if taps is not None:
+        taps["attn"] = x
+    x = x + conv_module(x, w, g)
+    if taps is not None:
+        taps["conv"] = x
+    x = x + 0.5 * _ffn(F.layer_norm(x, (d,), w["ffn2_ln_w"], w["ffn2_ln_b"], g.ln_eps), w, "ffn2")
+    return F.layer_norm(x, (d,), w["final_ln_w"], w["final_ln_b"], g.ln_eps)
+
+
+def input_projection(feats, w, g: Geometry):
+    y = F.layer_norm(feats, (g.feat_dim,), w["fp_ln_w"], w["fp_ln_b"], g.ln_eps)
+    return F.linear(y, w["fp_w"], w["fp_b"])
+
+
+@torch.no_grad()
+def forward(feats, lengths, weights: dict, g: Geometry = G300, dtype=torch.float32, per_layer=False):
+    """weights: {'fp_ln_w','fp_ln_b','fp_w','fp_b','layers': [ {LAYER_KEYS...} ]}.
+    Returns hidden [B, T, d] (and the list of per-layer outputs when per_layer)."""
+    cast = lambda t: t.to(dtype)
+    top = {k: cast(v) for k, v in weights.items() if k != "layers"}
+    x = input_projection(cast(feats), top, g)
+    outs = [x]
+    for lw in weights["layers"]:
+        x = block(x, lengths, {k: cast(v) for k, v in lw.items()}, g)
+        outs.append(x)
+    return (x, outs) if per_layer else x

@@ -1,0 +1,282 @@
+"""GPU parity tests of the individual HIP operators, called through the C ABI (ctypes), against the
+CPU oracle / plain PyTorch float32 on the same seeded inputs.
+
+Tolerances (stated per test): float32 kernels are compared with absolute tolerances that reflect
+float32 round-off of the chosen algorithm; bf16-MFMA kernels are compared after rounding the same
+operands to bf16 on the CPU, so the remaining difference is accumulation order plus one output
+rounding.
+"""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from omnilingual_asr import _hip
+    return _hip
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def synth_pcm(batch, n, seed=1234):
+    g = torch.Generator().manual_seed(seed)
+    x = 0.1 * torch.randn((batch, n + 1), generator=g)
+    x = 0.5 * (x[:, 1:] + x[:, :-1])
+    t = torch.arange(n, dtype=torch.float64) / 16000.0
+    x = x + (0.1 * torch.sin(2 * math.pi * 440.0 * t)).to(torch.float32)[None, :]
+    return x.clamp(-1.0, 1.0).contiguous()
+
+
+# --------------------------------------------------------------------------------------------------
+# log-mel + normalisation
+
+@pytest.mark.parametrize("batch,n_list", [(2, [48000, 48000]), (3, [16000, 400, 15999]), (1, [480000])])
+def test_logmel_and_features_match_oracle(batch, n_list):
+    from oracle import logmel as O
+    from omnilingual_asr.engine_hip import HipEngine, pad_frames
+    H = _lib()
+    n_max = max(n_list)
+    stride = (n_max + 3) // 4 * 4
+    pcm = torch.zeros((batch, stride))
+    src = synth_pcm(batch, n_max)
+    for i, n in enumerate(n_list):
+        pcm[i, :n] = src[i, :n]
+    dev = torch.device("cuda")
+    pcm_d = pcm.to(dev)
+    nv = torch.tensor(n_list, dtype=torch.int32, device=dev)
+    frames = H.num_frames(n_max)
+    t_pad = pad_frames(frames // 2)
+    cap = 2 * t_pad
+    slots = int(H.lib().oasr_logmel_stats_slots(cap))
+    tables = torch.from_numpy(H.logmel_table_blob().view(np.int32)).to(dev)
+    lm = torch.full((batch, cap, 80), float("nan"), device=dev)
+    stats = torch.zeros((batch, slots, 80, 2), device=dev)
+    feats = torch.full((batch, t_pad, 160), float("nan"), device=dev)
+    lens = torch.zeros((batch,), dtype=torch.int32, device=dev)
+    H.check(H.lib().oasr_logmel_f32(pcm_d.data_ptr(), stride, nv.data_ptr(), batch, cap, tables.data_ptr(),
+                                    lm.data_ptr(), stats.data_ptr(), _stream()))
+    H.check(H.lib().oasr_feature_norm_stack(lm.data_ptr(), stats.data_ptr(), nv.data_ptr(), batch, cap, t_pad,
+                                            feats.data_ptr(), lens.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    lm_h, feats_h, lens_h = lm.cpu().numpy(), feats.cpu().numpy(), lens.cpu().numpy()
+    for i, n in enumerate(n_list):
+        nf = O.num_frames(n)
+        assert lens_h[i] == nf // 2                       # integer frame counts are bit-exact
+        if nf == 0:
+            continue
+        ref_lm = O.logmel(pcm[i, :n].numpy())
+        # float32 FFT of signals scaled to 2^15: |err| in ln(power) well below 1e-3 for non-floor bins
+        np.testing.assert_allclose(lm_h[i, :nf], ref_lm, atol=2e-3, rtol=0)
+        assert np.isnan(lm_h[i, nf:]).all()               # rows past the last frame are untouched
+        if nf >= 2:
+            ref_f = O.features(pcm[i, :n].numpy())
+            np.testing.assert_allclose(feats_h[i, : nf // 2], ref_f, atol=5e-3, rtol=0)
+        assert (feats_h[i, nf // 2:] == 0).all()          # padding rows are zero
+
+
+# --------------------------------------------------------------------------------------------------
+# LayerNorm
+
+@pytest.mark.parametrize("d", [160, 512, 1024, 4096])
+@pytest.mark.parametrize("bf16", [0, 1])
+@pytest.mark.parametrize("swish", [0, 1])
+def test_layernorm(d, bf16, swish):
+    if d == 160 and swish:
+        pytest.skip("swish epilogue is not offered for the feature LayerNorm")
+    H = _lib()
+    g = torch.Generator().manual_seed(d + bf16)
+    rows = 1030
+    x = torch.randn((rows, d), generator=g) * 3.0 + 0.5
+    w = 1.0 + 0.2 * torch.randn((d,), generator=g)
+    b = 0.2 * torch.randn((d,), generator=g)
+    stride = 192 if d == 160 else d
+    dev = "cuda"
+    y = torch.full((rows, stride), float("nan"), device=dev, dtype=torch.bfloat16 if bf16 else torch.float32)
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    H.check(H.lib().oasr_layernorm(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), rows, d, stride,
+                                   1e-5, bf16, swish, _stream()))
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.layer_norm(x.double(), (d,), w.double(), b.double(), 1e-5)
+    if swish:
+        ref = ref * torch.sigmoid(ref)
+    got = y.float().cpu()
+    tol = 4e-2 if bf16 else 2e-5       # bf16 output: 2^-8 relative on values up to ~8
+    torch.testing.assert_close(got[:, :d].double(), ref, atol=tol, rtol=tol)
+    if stride > d:
+        assert (got[:, d:] == 0).all()
+
+
+def test_layernorm2_matches_two_layernorms():
+    H = _lib()
+    g = torch.Generator().manual_seed(7)
+    rows, d = 515, 1024
+    x = torch.randn((rows, d), generator=g) * 2.0
+    p = [1.0 + 0.1 * torch.randn((d,), generator=g) if i % 2 == 0 else 0.1 * torch.randn((d,), generator=g)
+         for i in range(4)]
+    xd = x.cuda()
+    pd = [t.cuda() for t in p]
+    y = torch.zeros((rows, d), device="cuda", dtype=torch.bfloat16)
+    H.check(H.lib().oasr_layernorm2(xd.data_ptr(), pd[0].data_ptr(), pd[1].data_ptr(), pd[2].data_ptr(),
+                                    pd[3].data_ptr(), y.data_ptr(), rows, d, 1e-5, _stream()))
+    torch.cuda.synchronize()
+    r1 = torch.nn.functional.layer_norm(x.double(), (d,), p[0].double(), p[1].double(), 1e-5)
+    r2 = torch.nn.functional.layer_norm(r1, (d,), p[2].double(), p[3].double(), 1e-5)
+    torch.testing.assert_close(xd.cpu().double(), r1, atol=2e-5, rtol=2e-5)
+    torch.testing.assert_close(y.float().cpu().double(), r2, atol=4e-2, rtol=4e-2)
+
+
+# --------------------------------------------------------------------------------------------------
+# GEMM
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 256, 64), (512, 768, 192), (1024, 512, 1024)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
+def test_gemm_epilogues(m, n, k, epi):
+    H = _lib()
+    g = torch.Generator().manual_seed(100 * epi + k)
+    # asymmetric, non-constant operands so that a transposed or permuted tile cannot pass
+    a = _bf(torch.randn((m, k), generator=g))
+    w = _bf(torch.randn((n, k), generator=g) / math.sqrt(k))
+    bias = torch.randn((n,), generator=g)
+    resid = torch.randn((m, n), generator=g)
+    ad, wd, bd = a.cuda(), w.cuda(), bias.cuda()
+    acc = a.double() @ w.double().t()
+    if epi == H.EPI_GLU_BF16:
+        from omnilingual_asr.weights import glu_interleave
+        wd = _bf(glu_interleave(w.float())).cuda()
+        c = torch.full((m, n // 2), float("nan"), device="cuda", dtype=torch.bfloat16)
+        H.check(H.lib().oasr_gemm_bf16(ad.data_ptr(), wd.data_ptr(), None, None, c.data_ptr(), m, n, k, 1.0, epi, _stream()))
+        ref = acc[:, : n // 2] * torch.sigmoid(acc[:, n // 2:])
+    elif epi == H.EPI_RESIDUAL_F32:
+        c = resid.cuda().clone()
+        H.check(H.lib().oasr_gemm_bf16(ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), c.data_ptr(), c.data_ptr(), m, n, k, 0.5, epi, _stream()))
+        ref = resid.double() + 0.5 * (acc + bias.double())
+    elif epi == H.EPI_BIAS_F32:
+        c = torch.full((m, n), float("nan"), device="cuda")
+        H.check(H.lib().oasr_gemm_bf16(ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), None, c.data_ptr(), m, n, k, 1.0, epi, _stream()))
+        ref = acc + bias.double()
+    else:
+        c = torch.full((m, n), float("nan"), device="cuda", dtype=torch.bfloat16)
+        H.check(H.lib().oasr_gemm_bf16(ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), None, c.data_ptr(), m, n, k, 1.0, epi, _stream()))
+        ref = acc + bias.double()
+        if epi == H.EPI_BIAS_SWISH_BF16:
+            ref = ref * torch.sigmoid(ref)
+    torch.cuda.synchronize()
+    got = c.float().cpu().double()
+    assert torch.isfinite(got).all()
+    # operands are exact bf16 on both sides: float32 accumulation error ~1e-5; bf16 outputs add 2^-8 relative
+    tol = 2e-4 if c.dtype == torch.float32 else 2.5e-2
+    torch.testing.assert_close(got, ref, atol=tol, rtol=tol)
+
+
+def test_gemm_identity_asymmetric():
+    """A = I against an asymmetric W catches a swapped row/column map in the C write."""
+    H = _lib()
+    m = n = k = 256
+    a = _bf(torch.eye(m))
+    w = _bf((torch.arange(n)[:, None] * 3 + torch.arange(k)[None, :] % 7).float() % 64)
+    c = torch.zeros((m, n), device="cuda")
+    H.check(H.lib().oasr_gemm_bf16(a.cuda().data_ptr(), w.cuda().data_ptr(), None, None, c.data_ptr(), m, n, k, 1.0,
+                                   H.EPI_BIAS_F32, _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(c.cpu(), w.float().t().contiguous())
+
+
+def test_gemm_rejects_bad_shapes():
+    H = _lib()
+    z = torch.zeros((256, 256), device="cuda", dtype=torch.bfloat16)
+    rc = H.lib().oasr_gemm_bf16(z.data_ptr(), z.data_ptr(), None, None, z.data_ptr(), 100, 256, 64, 1.0, 0, _stream())
+    assert rc == -1 and b"multiples" in H.lib().oasr_last_error()
+
+
+# --------------------------------------------------------------------------------------------------
+# attention
+
+def _attention_ref(qkv, dist_emb, lengths, n_heads, left, right):
+    b, t, d3 = qkv.shape
+    d = d3 // 3
+    dh = d // n_heads
+    q, k, v = [x.reshape(b, t, n_heads, dh).transpose(1, 2).double() for x in qkv.split(d, dim=-1)]
+    pos = torch.arange(t)
+    dist = (pos[None, :] - pos[:, None]).clamp(-left, right) + left
+    scores = q @ k.transpose(-1, -2)
+    qe = q @ dist_emb.double().t()
+    scores = (scores + torch.gather(qe, 3, dist[None, None].expand(b, n_heads, t, t))) / math.sqrt(dh)
+    ok = pos[None, :] < lengths[:, None]
+    scores = scores.masked_fill(~ok[:, None, None, :], float("-inf"))
+    p = torch.softmax(scores, dim=-1)
+    return (p @ v).transpose(1, 2).reshape(b, t, d)
+
+
+@pytest.mark.parametrize("batch,t_pad,lens,heads", [(2, 256, [256, 131], 2), (1, 1504, [1499], 1),
+                                                    (3, 96, [96, 1, 70], 4)])
+def test_attention_relkey(batch, t_pad, lens, heads):
+    H = _lib()
+    g = torch.Generator().manual_seed(t_pad + heads)
+    d = heads * 64
+    qkv = _bf(torch.randn((batch, t_pad, 3 * d), generator=g))
+    emb = torch.zeros((96, 64))
+    emb[:73] = torch.randn((73, 64), generator=g)
+    emb = _bf(emb)
+    lengths = torch.tensor(lens, dtype=torch.int32)
+    rows = (batch * t_pad + 255) // 256 * 256
+    qkv_d = torch.zeros((rows, 3 * d), dtype=torch.bfloat16, device="cuda")
+    qkv_d[: batch * t_pad] = qkv.reshape(-1, 3 * d).cuda()
+    ctx = torch.zeros((rows, d), dtype=torch.bfloat16, device="cuda")
+    H.check(H.lib().oasr_attention_relkey(qkv_d.data_ptr(), emb.cuda().data_ptr(), lengths.cuda().data_ptr(),
+                                          ctx.data_ptr(), batch, t_pad, heads, 64, 8, _stream()))
+    torch.cuda.synchronize()
+    ref = _attention_ref(qkv.float(), emb.float()[:73], lengths.long(), heads, 64, 8)
+    got = ctx[: batch * t_pad].float().cpu().reshape(batch, t_pad, d).double()
+    for i, n in enumerate(lens):
+        # P is rounded to bf16 before P.V and the output is bf16: 2^-8 relative on |ctx| <~ 3
+        torch.testing.assert_close(got[i, :n], ref[i, :n], atol=3e-2, rtol=3e-2)
+    assert torch.isfinite(got).all()
+
+
+def test_attention_online_softmax_rescale_is_exercised():
+    """A key late in the sequence that dominates every row forces the running maximum to jump at a
+    later tile, so the rescale of the accumulated output is actually taken."""
+    H = _lib()
+    batch, t_pad, heads, d = 1, 256, 1, 64
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn((batch, t_pad, 3 * d), generator=g) * 0.5
+    qkv[0, :, :d] = qkv[0, :, :d].abs()                 # positive queries
+    qkv[0, 200, d:2 * d] = 6.0                          # one key with a large positive dot product
+    qkv = _bf(qkv)
+    emb = _bf(torch.zeros((96, 64)))
+    lengths = torch.tensor([t_pad], dtype=torch.int32)
+    ctx = torch.zeros((256, d), dtype=torch.bfloat16, device="cuda")
+    H.check(H.lib().oasr_attention_relkey(qkv.reshape(-1, 3 * d).cuda().data_ptr(), emb.cuda().data_ptr(),
+                                          lengths.cuda().data_ptr(), ctx.data_ptr(), batch, t_pad, heads, 64, 8, _stream()))
+    torch.cuda.synchronize()
+    ref = _attention_ref(qkv.float(), emb.float()[:73], lengths.long(), heads, 64, 8)
+    torch.testing.assert_close(ctx.float().cpu().reshape(1, t_pad, d).double(), ref, atol=3e-2, rtol=3e-2)
+
+
+# --------------------------------------------------------------------------------------------------
+# depthwise convolution
+
+@pytest.mark.parametrize("batch,t_pad,d", [(2, 64, 512), (1, 1504, 1024)])
+def test_dwconv_causal(batch, t_pad, d):
+    H = _lib()
+    g = torch.Generator().manual_seed(d)
+    x = _bf(torch.randn((batch, t_pad, d), generator=g))
+    w = torch.randn((d, 31), generator=g) / math.sqrt(31)
+    y = torch.full((batch * t_pad, d), float("nan"), device="cuda")
+    H.check(H.lib().oasr_dwconv_causal(x.reshape(-1, d).cuda().data_ptr(), w.t().contiguous().cuda().data_ptr(),
+                                       y.data_ptr(), batch, t_pad, d, 31, _stream()))
+    torch.cuda.synchronize()
+    xt = torch.nn.functional.pad(x.double().transpose(1, 2), (30, 0))
+    ref = torch.nn.functional.conv1d(xt, w.double()[:, None, :], groups=d).transpose(1, 2)
+    torch.testing.assert_close(y.cpu().double().reshape(batch, t_pad, d), ref, atol=1e-5, rtol=1e-5)
