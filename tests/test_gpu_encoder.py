@@ -91,11 +91,11 @@ def test_graph_replay_equals_eager():
     dev = torch.device("cuda")
     pcm = synth_pcm(2, 48000, seed=8).to(dev)
     nv = torch.tensor([48000, 40000], dtype=torch.int32, device=dev)
-    h_eager, _ = eng.step(pcm, nv)
+    h_eager, lens = eng.step(pcm, nv)
     h_eager = h_eager.clone()
-    h_graph, _ = eng.step_graph(pcm, nv)
-    torch.cuda.synchronize()
-    assert torch.equal(h_eager, h_graph)      # same kernels, same order: bit-identical
-    h_graph2, _ = eng.step_graph(pcm, nv)
-    torch.cuda.synchronize()
-    assert torch.equal(h_eager, h_graph2)
+    lens = lens.cpu().tolist()
+    for _ in range(2):
+        h_graph, _ = eng.step_graph(pcm, nv)
+        torch.cuda.synchronize()
+        for i, n in enumerate(lens):      # same kernels, same order: valid rows are bit-identical
+            assert torch.equal(h_eager[i, :n], h_graph[i, :n])

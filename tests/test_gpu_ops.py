@@ -186,7 +186,8 @@ def test_gemm_identity_asymmetric():
     a = _bf(torch.eye(m))
     w = _bf((torch.arange(n)[:, None] * 3 + torch.arange(k)[None, :] % 7).float() % 64)
     c = torch.zeros((m, n), device="cuda")
-    H.check(H.lib().oasr_gemm_bf16(a.cuda().data_ptr(), w.cuda().data_ptr(), None, None, c.data_ptr(), m, n, k, 1.0,
+    ad, wd = a.cuda(), w.cuda()
+    H.check(H.lib().oasr_gemm_bf16(ad.data_ptr(), wd.data_ptr(), None, None, c.data_ptr(), m, n, k, 1.0,
                                    H.EPI_BIAS_F32, _stream()))
     torch.cuda.synchronize()
     assert torch.equal(c.cpu(), w.float().t().contiguous())
@@ -233,7 +234,8 @@ def test_attention_relkey(batch, t_pad, lens, heads):
     qkv_d = torch.zeros((rows, 3 * d), dtype=torch.bfloat16, device="cuda")
     qkv_d[: batch * t_pad] = qkv.reshape(-1, 3 * d).cuda()
     ctx = torch.zeros((rows, d), dtype=torch.bfloat16, device="cuda")
-    H.check(H.lib().oasr_attention_relkey(qkv_d.data_ptr(), emb.cuda().data_ptr(), lengths.cuda().data_ptr(),
+    emb_d, len_d = emb.cuda(), lengths.cuda()
+    H.check(H.lib().oasr_attention_relkey(qkv_d.data_ptr(), emb_d.data_ptr(), len_d.data_ptr(),
                                           ctx.data_ptr(), batch, t_pad, heads, 64, 8, _stream()))
     torch.cuda.synchronize()
     ref = _attention_ref(qkv.float(), emb.float()[:73], lengths.long(), heads, 64, 8)
@@ -257,8 +259,9 @@ def test_attention_online_softmax_rescale_is_exercised():
     emb = _bf(torch.zeros((96, 64)))
     lengths = torch.tensor([t_pad], dtype=torch.int32)
     ctx = torch.zeros((256, d), dtype=torch.bfloat16, device="cuda")
-    H.check(H.lib().oasr_attention_relkey(qkv.reshape(-1, 3 * d).cuda().data_ptr(), emb.cuda().data_ptr(),
-                                          lengths.cuda().data_ptr(), ctx.data_ptr(), batch, t_pad, heads, 64, 8, _stream()))
+    qkv_d, emb_d, len_d = qkv.reshape(-1, 3 * d).cuda(), emb.cuda(), lengths.cuda()
+    H.check(H.lib().oasr_attention_relkey(qkv_d.data_ptr(), emb_d.data_ptr(), len_d.data_ptr(), ctx.data_ptr(),
+                                          batch, t_pad, heads, 64, 8, _stream()))
     torch.cuda.synchronize()
     ref = _attention_ref(qkv.float(), emb.float()[:73], lengths.long(), heads, 64, 8)
     torch.testing.assert_close(ctx.float().cpu().reshape(1, t_pad, d).double(), ref, atol=3e-2, rtol=3e-2)
@@ -274,8 +277,8 @@ def test_dwconv_causal(batch, t_pad, d):
     x = _bf(torch.randn((batch, t_pad, d), generator=g))
     w = torch.randn((d, 31), generator=g) / math.sqrt(31)
     y = torch.full((batch * t_pad, d), float("nan"), device="cuda")
-    H.check(H.lib().oasr_dwconv_causal(x.reshape(-1, d).cuda().data_ptr(), w.t().contiguous().cuda().data_ptr(),
-                                       y.data_ptr(), batch, t_pad, d, 31, _stream()))
+    xd, wd = x.reshape(-1, d).cuda(), w.t().contiguous().cuda()
+    H.check(H.lib().oasr_dwconv_causal(xd.data_ptr(), wd.data_ptr(), y.data_ptr(), batch, t_pad, d, 31, _stream()))
     torch.cuda.synchronize()
     xt = torch.nn.functional.pad(x.double().transpose(1, 2), (30, 0))
     ref = torch.nn.functional.conv1d(xt, w.double()[:, None, :], groups=d).transpose(1, 2)
