@@ -1,0 +1,382 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/.  TEST INFRASTRUCTURE ONLY.
+
+Run in the BUILD container only (`python oracle/gen_golden.py`); neither the reference nor
+`transformers` is needed on the GPU box, which reads just the committed fixtures.
+
+Part A — reference_host.json: outputs of the reference's own functions, obtained by importing
+  /root/reference/src/omnilingual_asr (pure Python; `google.genai`, `subprocess.run` and
+  `time.sleep` are replaced by in-memory stubs so nothing leaves the process).  Pins timestamp and
+  response parsing, the chunk plan and gate, chunk offsetting and merge order, the progress
+  protocol and the retry schedule.
+Part B — standin_logmel.npz / standin_encoder.npz: outputs of an INDEPENDENT third-party
+  implementation installed in this container (transformers' SeamlessM4TFeatureExtractor and
+  Wav2Vec2BertModel built from a config with seeded random weights, never from_pretrained).  It is
+  not the reference — the reference has no feature extractor or encoder — and only cross-checks the
+  geometry this build declares.
+"""
+
+from __future__ import annotations
+
+import dataclasses
+import io
+import json
+import sys
+import types
+from contextlib import redirect_stdout
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+GOLDEN = ROOT / "tests" / "golden"
+REF_SRC = Path("/root/reference/src")
+REF_WAV = Path("/root/reference/gettysburg.wav")
+
+
+# ----------------------------------------------------------------------------------------------------
+# Part A
+
+class _FakePart:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    @classmethod
+    def from_bytes(cls, data, mime_type):
+        return cls(inline_bytes=len(data), mime_type=mime_type)
+
+
+class _FakeModels:
+    def __init__(self, owner):
+        self.owner = owner
+
+    def generate_content(self, model, contents, config):
+        self.owner.calls.append({"model": model,
+                                 "parts": [dict(p.__dict__) if hasattr(p, "__dict__") else str(p)
+                                           for p in contents[0].parts]})
+        return types.SimpleNamespace(text=self.owner.canned)
+
+
+class _FakeClient:
+    calls: list = []
+    canned = "{}"
+
+    def __init__(self, api_key=None):
+        self.models = _FakeModels(_FakeClient)
+
+
+def _install_fake_genai():
+    google = types.ModuleType("google")
+    genai = types.ModuleType("google.genai")
+    gtypes = types.ModuleType("google.genai.types")
+    for name in ("Part", "Content", "FileData", "GenerateContentConfig"):
+        setattr(gtypes, name, _FakePart)
+    genai.Client = _FakeClient
+    genai.types = gtypes
+    google.genai = genai
+    sys.modules.update({"google": google, "google.genai": genai, "google.genai.types": gtypes})
+
+
+def _asdict(result):
+    return dataclasses.asdict(result)
+
+
+CANNED_RESPONSES = {
+    "plain": json.dumps({
+        "summary": "Two speakers, neutral.", "detected_emotions": ["neutral"], "speaker_count": 2,
+        "segments": [
+            {"speaker": "Speaker 1", "timestamp_start": "0:00", "timestamp_end": "0:04",
+             "content": "Four score and seven years ago", "languages": [{"name": "English", "code": "en"}],
+             "emotion": "neutral", "translation": None},
+            {"speaker": "Speaker 2", "timestamp_start": "00:01:05", "timestamp_end": "00:01:02.5",
+             "content": "hola, amigos", "languages": [{"name": "Spanish", "code": "es"}, {"name": "English", "code": "en"}],
+             "emotion": "happy", "translation": "hello, friends"},
+            {"timestamp_start": "12.25", "timestamp_end": "a:b", "content": "x"},
+        ]}),
+    "fenced": "Here you go:\n```json\n" + json.dumps({
+        "summary": "", "segments": [
+            {"speaker": "A", "timestamp_start": "1:2:3:4", "timestamp_end": "", "content": "legacy",
+             "language": "Lisu", "language_code": "lis", "emotion": "sad"},
+            {"speaker": "A", "timestamp_start": "1.5:00", "timestamp_end": "0:02", "content": "frac minutes",
+             "language_code": "lis"},
+            {"speaker": "B", "timestamp_start": "0:03", "timestamp_end": "0:09", "content": "no code",
+             "languages": [{"name": "Unknown"}]},
+        ]}) + "\n```\nthanks",
+    "garbage": "this is not json at all",
+    "empty_object": "{}",
+}
+
+TIMESTAMPS = ["", None, "1:05", "01:02:03.5", "12.25", "a:b", "1:2:3:4", " 2:30 ", "1.5:00", "0:59.999",
+              "10:00:00", "-1:30", "7", "1e2", "00:00", "3:", ":3"]
+MIME_NAMES = ["a.wav", "b.MP3", "c.aiff", "d.aac", "e.ogg", "f.flac", "g.m4a", "h.xyz", "noext", "x.WAV"]
+DURATIONS = [0.0, 17.577, 359.9, 360.0, 360.1, 600.0, 601.0, 34200.0]
+CHUNKS = [300.0, 30.0]
+
+
+def part_a() -> dict:
+    _install_fake_genai()
+    sys.path.insert(0, str(REF_SRC))
+    from omnilingual_asr.models.inference import gemini_pipeline as G
+    from omnilingual_asr.diarization import pipeline as P
+    import omnilingual_asr as pkg
+
+    out = {"reference_version": pkg.__version__, "generator": "oracle/gen_golden.py part A",
+           "constants": {"CHUNK_DURATION_SECONDS": G.CHUNK_DURATION_SECONDS,
+                         "MIN_DURATION_FOR_CHUNKING": G.MIN_DURATION_FOR_CHUNKING,
+                         "MAX_PARALLEL_CHUNKS": G.MAX_PARALLEL_CHUNKS}}
+    out["parse_timestamp"] = [[t, G.parse_timestamp(t)] for t in TIMESTAMPS]
+    out["get_mime_type"] = [[n, G.get_mime_type(Path(n))] for n in MIME_NAMES]
+
+    pipe = G.GeminiASRPipeline(api_key="k")
+    out["parse_response"] = {name: _asdict(pipe._parse_response(text)) for name, text in CANNED_RESPONSES.items()}
+    out["parse_response_inputs"] = CANNED_RESPONSES
+    out["build_prompt_hint_suffix"] = pipe._build_prompt(language="Lisu", speaker_count="2")[
+        len(G.TRANSCRIPTION_PROMPT.strip()):]
+
+    # ---- chunk plans: stub the duration probe and the ffmpeg calls, record what would be cut
+    plans = []
+    real_run, real_dur = G.subprocess.run, G.get_audio_duration
+    for dur in DURATIONS:
+        for chunk in CHUNKS:
+            cut = []
+
+            def fake_run(cmd, **kw):
+                cut.append({"ss": cmd[cmd.index("-ss") + 1], "t": cmd[cmd.index("-t") + 1],
+                            "name": Path(cmd[-1]).name, "copy": "-c" in cmd})
+                return types.SimpleNamespace(stdout="", returncode=0)
+
+            G.subprocess.run = fake_run
+            G.get_audio_duration = lambda p, d=dur: d
+            res = G.split_audio_into_chunks(Path("/x/long_audio.mp3"), chunk_duration=chunk, output_dir=Path("/tmp/o"))
+            plans.append({"duration": dur, "chunk": chunk, "use_chunking": dur > G.MIN_DURATION_FOR_CHUNKING,
+                          "starts": [s for _, s in res], "names": [Path(p).name for p, _ in res],
+                          "ffmpeg": cut})
+    G.subprocess.run, G.get_audio_duration = real_run, real_dur
+    out["chunk_plans"] = plans
+
+    # ---- chunked merge: canned per-chunk results, one empty, one failing
+    def seg(t0, t1, text, lang=None):
+        langs = [{"name": lang[0], "code": lang[1]}] if lang else []
+        return {"speaker": "Speaker 1", "timestamp_start": t0, "timestamp_end": t1, "content": text,
+                "languages": langs, "emotion": "neutral"}
+
+    per_chunk = {
+        0.0: json.dumps({"summary": "first.", "segments": [seg("0:01", "0:05", "a", ("English", "en")),
+                                                             seg("4:58", "5:03", "b", ("English", "en"))]}),
+        300.0: json.dumps({"summary": "", "segments": []}),
+        600.0: "RAISE",
+        900.0: json.dumps({"summary": "last.", "segments": [seg("0:00", "0:00", "c", ("Lisu", "lis"))]}),
+    }
+    pipe2 = G.GeminiASRPipeline(api_key="k")
+    offsets = iter(sorted(per_chunk))
+    chunk_files = {f"chunk_{i:04d}.wav": off for i, off in enumerate(sorted(per_chunk))}
+
+    def fake_split(audio_path, output_dir=None, **kw):
+        return [(Path(output_dir) / name, off) for name, off in chunk_files.items()]
+
+    def fake_transcribe(audio_path, *, progress_callback=None, language=None, speaker_count=None):
+        off = chunk_files[Path(audio_path).name]
+        text = per_chunk[off]
+        if text == "RAISE":
+            raise ValueError("boom")
+        return pipe2._parse_response(text)
+
+    real_split = G.split_audio_into_chunks
+    G.split_audio_into_chunks = fake_split
+    pipe2.transcribe = fake_transcribe
+    progress = []
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        merged = pipe2.transcribe_chunked(Path("/x/long.wav"), progress_callback=lambda s, i: progress.append([s, i]))
+    G.split_audio_into_chunks = real_split
+    out["chunked_merge"] = {"per_chunk_inputs": {str(k): v for k, v in per_chunk.items()},
+                            "merged": _asdict(merged), "progress": progress, "stdout": buf.getvalue()}
+
+    # ---- short path through the top-level class on gettysburg.wav (plumbing), canned JSON
+    _FakeClient.calls = []
+    _FakeClient.canned = CANNED_RESPONSES["plain"]
+    top = P.GeminiDiarizedTranscriptionPipeline(api_key="k")
+    progress = []
+    segs = top.transcribe(str(REF_WAV), word_timestamps=True, progress_callback=lambda s, i: progress.append([s, i]),
+                          language="en", unknown_kwarg=1)
+    out["short_path"] = {"progress": progress, "segments": [dataclasses.asdict(s) for s in segs],
+                         "summary": top.summary, "detected_languages": top.detected_languages,
+                         "inline_bytes": _FakeClient.calls[0]["parts"][0].get("inline_bytes"),
+                         "mime": _FakeClient.calls[0]["parts"][0].get("mime_type"),
+                         "duration_probe": G.get_audio_duration(REF_WAV)}
+    out["segment_fields"] = [f.name for f in dataclasses.fields(P.DiarizedTranscriptSegment)]
+    out["segment_defaults"] = {f.name: f.default for f in dataclasses.fields(P.DiarizedTranscriptSegment)
+                               if f.default is not dataclasses.MISSING}
+    try:
+        segs[0].start = 1.0
+        frozen = False
+    except dataclasses.FrozenInstanceError:
+        frozen = True
+    out["segment_frozen"] = frozen
+
+    # ---- <=1 chunk fall-through of the chunked path: progress steps repeat
+    pipe3 = G.GeminiASRPipeline(api_key="k")
+    G.get_audio_duration = lambda p: 0.0
+    progress = []
+    pipe3.transcribe_chunked(REF_WAV, progress_callback=lambda s, i: progress.append([s, i]))
+    G.get_audio_duration = real_dur
+    out["chunked_fallthrough_progress"] = progress
+
+    # ---- retry schedule
+    import time as _time
+    sleeps = []
+    real_sleep = _time.sleep
+    _time.sleep = lambda s: sleeps.append(s)
+    pipe4 = G.GeminiASRPipeline(api_key="k")
+    attempts = []
+
+    def always_fail(*a, **k):
+        attempts.append(1)
+        raise ValueError("nope %d" % len(attempts))
+
+    pipe4.transcribe = always_fail
+    try:
+        pipe4.transcribe_with_retry(REF_WAV)
+        msg = None
+    except RuntimeError as e:
+        msg = str(e)
+    sleeps_fail = list(sleeps)
+    sleeps.clear()
+    attempts2 = []
+
+    def fail_once(*a, **k):
+        attempts2.append(1)
+        if len(attempts2) == 1:
+            raise ValueError("transient")
+        return G.GeminiTranscriptionResult(summary="ok")
+
+    pipe4.transcribe = fail_once
+    res = pipe4.transcribe_with_retry(REF_WAV)
+    _time.sleep = real_sleep
+    out["retry"] = {"all_fail": {"attempts": len(attempts), "sleeps": sleeps_fail, "error": msg},
+                    "fail_once": {"attempts": len(attempts2), "sleeps": list(sleeps), "summary": res.summary}}
+    sys.path.remove(str(REF_SRC))
+    for m in [m for m in sys.modules if m == "omnilingual_asr" or m.startswith("omnilingual_asr.")]:
+        del sys.modules[m]
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------
+# Part B
+
+def part_b() -> dict:
+    import torch
+    from transformers import SeamlessM4TFeatureExtractor, Wav2Vec2BertConfig, Wav2Vec2BertModel
+
+    sys.path.insert(0, str(ROOT))
+    from oracle import conformer as OC
+    from oracle import logmel as OL
+
+    info = {}
+    fe = SeamlessM4TFeatureExtractor()
+    rng = np.random.default_rng(0)
+    waves = {"noise_1s": (0.1 * rng.standard_normal(16000)).astype(np.float32),
+             "tone_odd": (0.3 * np.sin(2 * np.pi * 523.25 * np.arange(16400) / 16000.0)
+                          + 0.01 * rng.standard_normal(16400)).astype(np.float32)}
+    store = {}
+    for name, wav in waves.items():
+        enc = fe(wav, sampling_rate=16000, return_tensors="np")
+        feats, mask = enc["input_features"][0], enc["attention_mask"][0]
+        raw = fe._extract_fbank_features(wav)
+        store[name + "_pcm"] = wav
+        store[name + "_logmel"] = raw.astype(np.float32)
+        store[name + "_features"] = feats.astype(np.float32)
+        store[name + "_mask"] = mask.astype(np.int32)
+        mine = OL.features(wav)
+        n = int(mask.sum())
+        info[name] = {"frames": int(raw.shape[0]), "valid_stacked": n,
+                      "max_abs_diff_logmel": float(np.abs(OL.logmel(wav) - raw).max()),
+                      "max_abs_diff_features": float(np.abs(mine[:n] - feats[:n]).max())}
+    np.savez_compressed(GOLDEN / "standin_logmel.npz", **store)
+
+    def convert(model, n_layers):
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        w = {"fp_ln_w": sd["feature_projection.layer_norm.weight"], "fp_ln_b": sd["feature_projection.layer_norm.bias"],
+             "fp_w": sd["feature_projection.projection.weight"], "fp_b": sd["feature_projection.projection.bias"],
+             "layers": []}
+        for i in range(n_layers):
+            p = f"encoder.layers.{i}."
+            L = {}
+            for a, b in (("ffn1", "ffn1"), ("ffn2", "ffn2")):
+                L[a + "_ln_w"], L[a + "_ln_b"] = sd[p + b + "_layer_norm.weight"], sd[p + b + "_layer_norm.bias"]
+                L[a + "_w1"], L[a + "_b1"] = sd[p + b + ".intermediate_dense.weight"], sd[p + b + ".intermediate_dense.bias"]
+                L[a + "_w2"], L[a + "_b2"] = sd[p + b + ".output_dense.weight"], sd[p + b + ".output_dense.bias"]
+            L["attn_ln_w"], L["attn_ln_b"] = sd[p + "self_attn_layer_norm.weight"], sd[p + "self_attn_layer_norm.bias"]
+            for a, b in (("q", "linear_q"), ("k", "linear_k"), ("v", "linear_v"), ("o", "linear_out")):
+                L["w" + a], L["b" + a] = sd[p + "self_attn." + b + ".weight"], sd[p + "self_attn." + b + ".bias"]
+            L["dist_emb"] = sd[p + "self_attn.distance_embedding.weight"]
+            L["conv_ln_w"], L["conv_ln_b"] = sd[p + "conv_module.layer_norm.weight"], sd[p + "conv_module.layer_norm.bias"]
+            L["pw1"] = sd[p + "conv_module.pointwise_conv1.weight"][:, :, 0]
+            L["dw"] = sd[p + "conv_module.depthwise_conv.weight"][:, 0, :]
+            L["dw_ln_w"], L["dw_ln_b"] = sd[p + "conv_module.depthwise_layer_norm.weight"], sd[p + "conv_module.depthwise_layer_norm.bias"]
+            L["pw2"] = sd[p + "conv_module.pointwise_conv2.weight"][:, :, 0]
+            L["final_ln_w"], L["final_ln_b"] = sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"]
+            w["layers"].append({k: L[k] for k in OC.LAYER_KEYS})
+        return w
+
+    def run(hidden, heads, inter, layers, t, lengths, seed, keep):
+        cfg = Wav2Vec2BertConfig(hidden_size=hidden, num_attention_heads=heads, intermediate_size=inter,
+                                 num_hidden_layers=layers)
+        torch.manual_seed(seed)
+        model = Wav2Vec2BertModel(cfg).eval()
+        with torch.no_grad():   # make LayerNorm gains/biases and biases non-trivial
+            for n_, p_ in model.named_parameters():
+                if n_.endswith("layer_norm.weight"):
+                    p_.add_(0.1 * torch.randn_like(p_))
+                elif n_.endswith(".bias"):
+                    p_.add_(0.05 * torch.randn_like(p_))
+        gen = torch.Generator().manual_seed(seed + 1)
+        feats = torch.randn((len(lengths), t, 160), generator=gen)
+        lens = torch.tensor(lengths, dtype=torch.int32)
+        mask = (torch.arange(t)[None, :] < lens[:, None]).long()
+        with torch.no_grad():
+            o = model(input_features=feats, attention_mask=mask, output_hidden_states=True)
+        w = convert(model, layers)
+        g = OC.Geometry(name="standin", d_model=hidden, ffn_dim=inter, n_heads=heads, n_layers=layers)
+        mine, per = OC.forward(feats, lens, w, g, per_layer=True)
+        diffs = []
+        for k in range(layers + 1):
+            d = 0.0
+            for b, n in enumerate(lengths):
+                d = max(d, float((per[k][b, :n] - o.hidden_states[k][b, :n]).abs().max()))
+            diffs.append(d)
+        if keep:
+            flat = {"feats": feats.numpy(), "lengths": lens.numpy()}
+            for k, h in enumerate(o.hidden_states):
+                flat[f"hidden_{k}"] = h.numpy()
+            for key, val in w.items():
+                if key != "layers":
+                    flat["w." + key] = val.numpy()
+            for i, L in enumerate(w["layers"]):
+                for key, val in L.items():
+                    flat[f"w.layers.{i}.{key}"] = val.numpy()
+            flat["geometry"] = np.array([hidden, inter, heads, layers], dtype=np.int32)
+            np.savez_compressed(GOLDEN / "standin_encoder.npz", **flat)
+        return diffs
+
+    info["encoder_small"] = {"config": "hidden 128, 2 heads, ffn 256, 2 blocks, T=101, lengths [101, 77]",
+                             "max_abs_diff_per_layer": run(128, 2, 256, 2, 101, [101, 77], 0, True)}
+    info["encoder_full_width_generation_time_only"] = {
+        "config": "hidden 1024, 16 heads, ffn 4096, 2 blocks, T=200, lengths [200, 150] (weights not stored)",
+        "max_abs_diff_per_layer": run(1024, 16, 4096, 2, 200, [200, 150], 1, False)}
+    return info
+
+
+def main():
+    GOLDEN.mkdir(parents=True, exist_ok=True)
+    a = part_a()
+    (GOLDEN / "reference_host.json").write_text(json.dumps(a, indent=1, sort_keys=True) + "\n")
+    # the reference's own sample file, used by the plumbing tests (BASELINE config 1)
+    (GOLDEN / "gettysburg.wav").write_bytes(REF_WAV.read_bytes())
+    b = part_b()
+    (GOLDEN / "standin_info.json").write_text(json.dumps(b, indent=1, sort_keys=True) + "\n")
+    print(json.dumps(b, indent=1))
+
+
+if __name__ == "__main__":
+    main()
