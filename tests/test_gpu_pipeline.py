@@ -1,0 +1,87 @@
+"""GPU tests of the boundary (Pipeline.transcribe with the default HIP engine) and size-independent
+properties of the device path at the BASELINE batch size."""
+
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_wav(path, seconds, rate=16000, seed=0):
+    rng = np.random.default_rng(seed)
+    x = (0.1 * rng.standard_normal(int(seconds * rate))).clip(-1, 1)
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(rate)
+        w.writeframes((x * 32767).astype("<i2").tobytes())
+
+
+def test_transcribe_gettysburg_on_hip_matches_oracle_records(golden_dir):
+    from omnilingual_asr import Pipeline, audio
+    from omnilingual_asr.weights import GEOMETRIES, init_random_weights
+    from oracle import conformer as OC
+    from oracle.engine import OracleEngine
+
+    pipe = Pipeline(model="GTINY", seed=4)
+    progress = []
+    segs = pipe.transcribe(str(golden_dir / "gettysburg.wav"), progress_callback=lambda s, i: progress.append((s, i)))
+    assert progress == [("uploading", 0), ("transcribing", 1), ("processing", 2), ("done", 3)]
+    assert len(segs) == 1 and segs[0].start == 0.0 and segs[0].end == 281233 / 16000.0
+    # same audio through the CPU oracle: frame count bit-exact, activity within the bf16 tolerance
+    pcm = audio.load_audio_16k(golden_dir / "gettysburg.wav")
+    g = GEOMETRIES["GTINY"]
+    og = OC.Geometry(name=g.name, d_model=g.d_model, ffn_dim=g.ffn_dim, n_heads=g.n_heads, n_layers=g.n_layers)
+    hidden, lens = OracleEngine(init_random_weights(g, 4), og).encode_batch(pcm[None, :], [len(pcm)])
+    rec = pipe.gemini._encode_chunks(pcm, np.array([[0, len(pcm)]]))[0]
+    assert rec.n_frames == int(lens[0]) == 878
+    assert rec.activity == pytest.approx(float(hidden[0, : lens[0]].abs().mean()), rel=5e-3)
+
+
+def test_chunked_transcribe_on_hip(tmp_path):
+    from omnilingual_asr import Pipeline
+
+    wav = tmp_path / "long.wav"
+    _write_wav(wav, 100.5)
+    pipe = Pipeline(model="GTINY", batch_size=3)
+    segs = pipe.transcribe(str(wav))
+    assert [s.start for s in segs] == [0.0, 30.0, 60.0, 90.0]
+    assert [s.end for s in segs] == [30.0, 60.0, 90.0, 100.5]
+    recs = pipe.gemini._encode_chunks(np.zeros(16000 * 100 + 8000, dtype=np.float32),
+                                      np.array([[0, 480000], [480000, 960000], [960000, 1440000], [1440000, 1608000]]))
+    assert [r.n_frames for r in recs] == [1499, 1499, 1499, 524]
+
+
+def test_full_size_batch_properties():
+    """Batch 32 x 30 s, G300 with 2 blocks (the per-block work is what scales; depth does not change
+    the properties): (1) an utterance's states do not depend on its batch neighbours or position,
+    (2) junk beyond an utterance's valid samples does not change its valid frames."""
+    import dataclasses
+    from omnilingual_asr.engine_hip import HipEngine
+    from omnilingual_asr.weights import GEOMETRIES
+    from tests.test_gpu_ops import synth_pcm
+
+    g = dataclasses.replace(GEOMETRIES["G300"], n_layers=2)
+    eng = HipEngine(g, seed=0)
+    dev = torch.device("cuda")
+    n = 480000
+    pcm = synth_pcm(32, n, seed=21).to(dev)
+    n_valid = [n] * 32
+    n_valid[5], n_valid[31] = 250000, 400
+    nv = torch.tensor(n_valid, dtype=torch.int32, device=dev)
+    hidden, lengths = eng.step(pcm, nv)
+    hidden = hidden.clone()
+    lens = lengths.cpu().tolist()
+    assert lens[0] == 1499 and lens[5] == 780 and lens[31] == 0
+    assert torch.isfinite(hidden).all()
+    for i in (0, 5, 17):
+        alone, l1 = eng.step(pcm[i:i + 1].contiguous(), nv[i:i + 1].contiguous())
+        assert int(l1[0]) == lens[i]
+        torch.testing.assert_close(alone[0, : lens[i]], hidden[i, : lens[i]], atol=0, rtol=0)
+    junk = pcm.clone()
+    junk[5, 250000:] = 1e3
+    h2, _ = eng.step(junk, nv)
+    torch.testing.assert_close(h2[5, : lens[5]], hidden[5, : lens[5]], atol=0, rtol=0)
