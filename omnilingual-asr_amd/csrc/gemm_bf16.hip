@@ -1,24 +1,84 @@
 // bf16 MFMA GEMM with fused epilogues for gfx950:  C[m][n] = epi( sum_k A[m][k] * W[n][k] ).
 //
-// Both operands are K-contiguous (activations [m][k], Linear weights [n][k]), so both tiles are
-// staged the same way: 256 rows x 64 k (128-byte rows) per K-step, copied HBM -> LDS directly by
+// Operands.  Both are K-contiguous (activations [m][k], Linear weights [n][k]), so both tiles are
+// staged the same way: 256 rows x 64 k (128-byte rows) per K-step, copied global -> LDS directly by
 // global_load_lds (16 bytes per lane, no VGPR round trip), double buffered.  The LDS image is
 // lane-linear per wave instruction, so the bank-conflict swizzle (16-byte chunk index XOR row&7)
-// is applied to the per-lane *source* address and again on the fragment read.
+// is applied to the per-lane *source* address and again on the fragment read (conflict-free
+// ds_read_b128).
 //
-// 8 wavefronts as 2 (m) x 4 (n); a wave owns 128 m x 64 n as 8 x 4 tiles of
-// v_mfma_f32_16x16x32_bf16.  The weight fragment is fed as the MFMA's A operand and the
-// activation fragment as B, so a lane ends up holding 4 consecutive n for one m and the epilogue
-// stores 8 (bf16) or 16 (f32) contiguous bytes per lane.
+// Tile and waves.  256 x 256 output tile, 8 wavefronts as 2 (m) x 4 (n); a wave owns 128 m x 64 n
+// as 8 x 4 tiles of v_mfma_f32_16x16x32_bf16.  The weight fragment is the MFMA's A operand and the
+// activation fragment its B operand, so a lane ends up holding 4 consecutive n for one m.
+//
+// Schedule (persistent ping-pong).  One work-group per CU walks a list of output tiles.  The 8
+// waves form two groups of 4 (waves 0-3: upper 128 rows, waves 4-7: lower 128 rows); each SIMD
+// hosts one wave of each group.  A phase is one K=32 step of a wave's sub-tile: a LOAD segment
+// (12 ds_read_b128, plus the global_load_lds of the next K-tile) and an MFMA segment (32 MFMAs),
+// separated by raw s_barriers.  Group B runs one barrier behind group A, so on every SIMD one wave
+// is in its MFMA segment while its partner is in its LOAD segment.  The K-steps of consecutive
+// output tiles form ONE continuous pipeline (global step g, LDS buffer g&1): the first K-tile of
+// the next output tile is staged while the current tile's last MFMAs run, and a wave's epilogue
+// overlaps its partner's MFMA segment.
+//
+//   barrier timeline (b_i = i-th barrier, L/M = load/MFMA segment of phase p = 2*step + khalf):
+//     A:  L0 |b0| M0 |b1| L1 |b2| M1 |b3| L2 ...
+//     B:     |b0| L0 |b1| M0 |b2| L1 |b3| M1 ...
+//   Step g+1 is staged into buffer (g+1)&1 during L(2g): every read of step g-1 (same buffer) was
+//   issued before b_(4g-1) and retired by the lgkmcnt wait that precedes the MFMAs, and both
+//   groups' L(2g) come after b_(4g-1).  Each wave waits vmcnt(0) at the end of L(2g+1), i.e. before
+//   b_(4g+2) (A) / b_(4g+3) (B); the first read of step g+1 comes after b_(4g+3).
+//
+// Epilogue.  Each 16-row slice of a wave's sub-tile is bounced through a wave-private LDS slab and
+// leaves as 16-byte-per-lane stores covering 8 rows x 128 contiguous bytes.  Outputs are written
+// with non-temporal stores: a GEMM output here is 100-400 MB, read next by another kernel, and
+// letting it allocate dirty lines in the 4 MiB L2 evicted the A/W panels the main loop re-reads
+// (measured: 453 -> 388 us on 48128 x 4096 x 1024).
 #include "oasr_common.h"
 
 namespace oasr {
 
 constexpr int BM = 256, BN = 256, BK = 64;
-constexpr int kTileBytes = BM * BK * 2;  // 32 KiB per operand per buffer
+constexpr int kTileBytes = BM * BK * 2;   // 32 KiB per operand per buffer
+constexpr int kEpiPitch = 144;            // bytes per slab row: 16-byte aligned, <= 2-way write conflicts
+constexpr int kEpiSlab = 16 * kEpiPitch;  // bytes per wave
+constexpr int kMaxCUs = 256;
+
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+#define OASR_RAW_BARRIER()                    \
+    do {                                      \
+        asm volatile("" ::: "memory");        \
+        __builtin_amdgcn_sched_barrier(0);    \
+        __builtin_amdgcn_s_barrier();         \
+        __builtin_amdgcn_sched_barrier(0);    \
+        asm volatile("" ::: "memory");        \
+    } while (0)
+
+// Orders this wave's LDS writes before its later LDS reads (DS operations of one wave execute in
+// order; this only pins the compiler).  The fences name the LDS address space only, so global
+// loads and stores (residual reads, output stores) stay free to move and overlap.
+#define OASR_WAVE_LDS_SYNC()                                    \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local"); \
+        __builtin_amdgcn_wave_barrier();                                 \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local"); \
+    } while (0)
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    bf2 v;
+    v[0] = (__bf16)a;
+    v[1] = (__bf16)b;
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+__device__ __forceinline__ void store_nt16(void* p, u32x4 v) {
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+}
 
 // Stage one 256 x 64 bf16 tile.  Each wave issues 4 global_load_lds of 1 KiB (8 rows each).
 __device__ __forceinline__ void stage_tile(const uint16_t* __restrict__ g, int64_t ld, int64_t row0,
@@ -33,28 +93,137 @@ __device__ __forceinline__ void stage_tile(const uint16_t* __restrict__ g, int64
     }
 }
 
+// acc[i][j]: lane (fr = lane & 15, fq = lane >> 4) holds C[mbase + 16 i + fr][nbase + 16 j + 4 fq + 0..3].
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[8][4], const float* __restrict__ bias,
+                                              const float* resid, void* C, int64_t N, float alpha,
+                                              int64_t mbase, int64_t nbase, int lane, char* slab) {
+    const int fr = lane & 15, fq = lane >> 4;
+    if (EPI == OASR_EPI_BIAS_BF16 || EPI == OASR_EPI_BIAS_SWISH_BF16) {
+        float4 bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            bv[j] = bias ? *reinterpret_cast<const float4*>(bias + nbase + j * 16 + fq * 4) : make_float4(0, 0, 0, 0);
+        const int rrow = lane >> 3, rchunk = lane & 7;   // read-back role: rows rrow, rrow + 8; 16-byte chunk
+        uint16_t* cbase = reinterpret_cast<uint16_t*>(C) + (mbase + rrow) * N + nbase + rchunk * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = acc[i][j];
+                v[0] += bv[j].x; v[1] += bv[j].y; v[2] += bv[j].z; v[3] += bv[j].w;
+                if (EPI == OASR_EPI_BIAS_SWISH_BF16) {
+                    v[0] = swishf(v[0]); v[1] = swishf(v[1]); v[2] = swishf(v[2]); v[3] = swishf(v[3]);
+                }
+                *reinterpret_cast<uint2*>(slab + fr * kEpiPitch + j * 32 + fq * 8) =
+                    make_uint2(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]));
+            }
+            OASR_WAVE_LDS_SYNC();
+            const u32x4 lo = *reinterpret_cast<const u32x4*>(slab + rrow * kEpiPitch + rchunk * 16);
+            const u32x4 hi = *reinterpret_cast<const u32x4*>(slab + (rrow + 8) * kEpiPitch + rchunk * 16);
+            OASR_WAVE_LDS_SYNC();
+            store_nt16(cbase + (int64_t)(i * 16) * N, lo);
+            store_nt16(cbase + (int64_t)(i * 16 + 8) * N, hi);
+        }
+    } else if (EPI == OASR_EPI_GLU_BF16) {
+        // interleaved weights: tiles j = 0, 2 hold values, j = 1, 3 their gates; N/2 output columns
+        const int rrow = lane >> 2, rchunk = lane & 3;   // 16 rows x 64 B
+        uint16_t* cbase = reinterpret_cast<uint16_t*>(C) + (mbase + rrow) * (N >> 1) + (nbase >> 1) + rchunk * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                const f32x4 v = acc[i][j], g = acc[i][j + 1];
+                *reinterpret_cast<uint2*>(slab + fr * kEpiPitch + (j >> 1) * 32 + fq * 8) =
+                    make_uint2(cvt_pk_bf16(v[0] * sigmoidf(g[0]), v[1] * sigmoidf(g[1])),
+                               cvt_pk_bf16(v[2] * sigmoidf(g[2]), v[3] * sigmoidf(g[3])));
+            }
+            OASR_WAVE_LDS_SYNC();
+            const u32x4 o = *reinterpret_cast<const u32x4*>(slab + rrow * kEpiPitch + rchunk * 16);
+            OASR_WAVE_LDS_SYNC();
+            store_nt16(cbase + (int64_t)(i * 16) * (N >> 1), o);
+        }
+    } else {  // float32 outputs: two 32-column halves per 16-row slice
+        const int rrow = lane >> 3, rchunk = lane & 7;
+        float4 bv[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            bv[h] = bias ? *reinterpret_cast<const float4*>(bias + nbase + h * 32 + rchunk * 4) : make_float4(0, 0, 0, 0);
+        // element index of (slice i, half h, row-pair r2) for this lane's read-back role
+        auto index_of = [&](int i, int h, int r2) {
+            return (mbase + i * 16 + rrow + 8 * r2) * N + nbase + h * 32 + rchunk * 4;
+        };
+        // The residual may alias the output (in-place update), so the compiler keeps loads and stores
+        // in program order: the residual of slice i+1 is therefore requested before slice i is stored,
+        // which keeps one slice of loads in flight instead of paying a memory round trip per store.
+        float4 rcur[2][2], rnext[2][2];
+        if (EPI == OASR_EPI_RESIDUAL_F32) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2) rcur[h][r2] = *reinterpret_cast<const float4*>(resid + index_of(0, h, r2));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (EPI == OASR_EPI_RESIDUAL_F32 && i + 1 < 8) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; ++r2)
+                        rnext[h][r2] = *reinterpret_cast<const float4*>(resid + index_of(i + 1, h, r2));
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+                    *reinterpret_cast<f32x4*>(slab + fr * kEpiPitch + jj * 64 + fq * 16) = acc[i][2 * h + jj];
+                OASR_WAVE_LDS_SYNC();
+                float4 v[2];
+                v[0] = *reinterpret_cast<const float4*>(slab + rrow * kEpiPitch + rchunk * 16);
+                v[1] = *reinterpret_cast<const float4*>(slab + (rrow + 8) * kEpiPitch + rchunk * 16);
+                OASR_WAVE_LDS_SYNC();
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2) {
+                    float4 o = make_float4(v[r2].x + bv[h].x, v[r2].y + bv[h].y, v[r2].z + bv[h].z, v[r2].w + bv[h].w);
+                    if (EPI == OASR_EPI_RESIDUAL_F32) {
+                        const float4 r = rcur[h][r2];
+                        o = make_float4(r.x + alpha * o.x, r.y + alpha * o.y, r.z + alpha * o.z, r.w + alpha * o.w);
+                    }
+                    store_nt16(reinterpret_cast<float*>(C) + index_of(i, h, r2),
+                               (u32x4){__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)});
+                }
+            }
+            if (EPI == OASR_EPI_RESIDUAL_F32) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; ++r2) rcur[h][r2] = rnext[h][r2];
+            }
+        }
+    }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_kernel(const uint16_t* __restrict__ A,
                                                         const uint16_t* __restrict__ W,
                                                         const float* __restrict__ bias,
-                                                        const float* resid, void* C, int64_t M,
-                                                        int64_t N, int64_t K, float alpha) {
-    __shared__ __attribute__((aligned(1024))) char smem[4 * kTileBytes];  // A0 A1 B0 B1
+                                                        const float* resid, void* C, int64_t N,
+                                                        int64_t K, float alpha, int n_tiles) {
+    __shared__ __attribute__((aligned(1024))) char smem[4 * kTileBytes + 8 * kEpiSlab];  // A0 A1 B0 B1 | slabs
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-
-    // XCD-aware block order: ids that share an XCD (id % 8) get a contiguous run of tiles, n
-    // fastest, so the A rows of an m-tile are fetched into one L2 and reused by all its n-tiles.
     const int tiles_n = (int)(N / BN);
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
-    }
-    const int64_t m0 = (int64_t)(bid / tiles_n) * BM;
-    const int64_t n0 = (int64_t)(bid % tiles_n) * BN;
+
+    // Tile list of this work-group.  Work-groups with equal blockIdx % 8 share an XCD (observed
+    // round-robin placement; used for L2 locality only, never for correctness): XCD x owns the
+    // contiguous tile range [x*n_tiles/8, (x+1)*n_tiles/8) and its work-groups interleave over it,
+    // so the tiles in flight on one XCD at any time are consecutive ones (n fastest) that share A
+    // and W panels.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int t_lo = (int)((int64_t)n_tiles * xcd / 8), t_hi = (int)((int64_t)n_tiles * (xcd + 1) / 8);
+    if (t_lo + slot >= t_hi) return;
+    const int my_tiles = (t_hi - t_lo - slot + per_xcd - 1) / per_xcd;  // tiles t_lo + slot + i*per_xcd
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -66,81 +235,69 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(const uint16_t* __restri
     // byte offset of this lane's 16-byte fragment inside a 16-row group, for the two k-halves
     const int off0 = fr * 128 + (((0 + fq) ^ (fr & 7)) << 4);
     const int off1 = fr * 128 + (((4 + fq) ^ (fr & 7)) << 4);
-
     const int nt = (int)(K / BK);
-    stage_tile(A, K, m0, 0, smem, wave, lane);
-    stage_tile(W, K, n0, 0, smem + 2 * kTileBytes, wave, lane);
+    const int total = my_tiles * nt;
+
+    auto tile_origin = [&](int i, int64_t& m0, int64_t& n0) {
+        const int tile = t_lo + slot + i * per_xcd;
+        m0 = (int64_t)(tile / tiles_n) * BM;
+        n0 = (int64_t)(tile % tiles_n) * BN;
+    };
+    auto stage_step = [&](int g) {  // global step g = i * nt + t  ->  buffer g & 1
+        int64_t m0, n0;
+        tile_origin(g / nt, m0, n0);
+        const int64_t k0 = (int64_t)(g % nt) * BK;
+        stage_tile(A, K, m0, k0, smem + (g & 1) * kTileBytes, wave, lane);
+        stage_tile(W, K, n0, k0, smem + (2 + (g & 1)) * kTileBytes, wave, lane);
+    };
+
+    stage_step(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    OASR_RAW_BARRIER();
+    if (wm == 1) OASR_RAW_BARRIER();  // group B runs one barrier behind
 
-    for (int t = 0; t < nt; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nt) {
-            stage_tile(A, K, m0, (int64_t)(t + 1) * BK, smem + (cur ^ 1) * kTileBytes, wave, lane);
-            stage_tile(W, K, n0, (int64_t)(t + 1) * BK, smem + (2 + (cur ^ 1)) * kTileBytes, wave, lane);
-        }
-        const char* sa = smem + cur * kTileBytes + (wm * 128) * 128;
-        const char* sb = smem + (2 + cur) * kTileBytes + (wn * 64) * 128;
+    bf16x8 xf[8], wf[4];
+    int g = 0;
+    for (int i = 0; i < my_tiles; ++i) {
+        for (int t = 0; t < nt; ++t, ++g) {
+            const int cur = g & 1;
+            const char* sa = smem + cur * kTileBytes + (wm * 128) * 128;
+            const char* sb = smem + (2 + cur) * kTileBytes + (wn * 64) * 128;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int off = kk ? off1 : off0;
-            bf16x8 xf[8], wf[4];
+            for (int kk = 0; kk < 2; ++kk) {
+                const int off = kk ? off1 : off0;
+                // ---- LOAD segment
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 128 + off);
+                for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 128 + off);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 128 + off);
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-
-    // ---- epilogue: lane holds C[m][n .. n+3], m = .. + (lane & 15), n = .. + 4 * (lane >> 4) ----------
-    const int64_t mrow0 = m0 + wm * 128 + fr;
-    const int64_t ncol0 = n0 + wn * 64 + fq * 4;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int64_t m = mrow0 + i * 16;
-        if (EPI == OASR_EPI_GLU_BF16) {
-#pragma unroll
-            for (int j = 0; j < 4; j += 2) {
-                const f32x4 v = acc[i][j], g = acc[i][j + 1];
-                const int64_t oc = ((n0 + wn * 64 + j * 16) >> 1) + fq * 4;
-                uint2 pk = make_uint2(pack_bf16x2(v[0] * sigmoidf(g[0]), v[1] * sigmoidf(g[1])),
-                                      pack_bf16x2(v[2] * sigmoidf(g[2]), v[3] * sigmoidf(g[3])));
-                *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(C) + m * (N >> 1) + oc) = pk;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t n = ncol0 + j * 16;
-                f32x4 v = acc[i][j];
-                if (bias != nullptr) {
-                    const float4 bv = *reinterpret_cast<const float4*>(bias + n);
-                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-                }
-                if (EPI == OASR_EPI_BIAS_SWISH_BF16) {
-                    v[0] = swishf(v[0]); v[1] = swishf(v[1]); v[2] = swishf(v[2]); v[3] = swishf(v[3]);
-                }
-                if (EPI == OASR_EPI_BIAS_BF16 || EPI == OASR_EPI_BIAS_SWISH_BF16) {
-                    uint2 pk = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(C) + m * N + n) = pk;
-                } else if (EPI == OASR_EPI_RESIDUAL_F32) {
-                    const float4 r = *reinterpret_cast<const float4*>(resid + m * N + n);
-                    float4 o = make_float4(r.x + alpha * v[0], r.y + alpha * v[1], r.z + alpha * v[2],
-                                           r.w + alpha * v[3]);
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(C) + m * N + n) = o;
+                for (int ii = 0; ii < 8; ++ii) xf[ii] = *reinterpret_cast<const bf16x8*>(sa + ii * 16 * 128 + off);
+                if (kk == 0) {
+                    if (g + 1 < total) stage_step(g + 1);
                 } else {
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(C) + m * N + n) =
-                        make_float4(v[0], v[1], v[2], v[3]);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
+                OASR_RAW_BARRIER();
+                // ---- MFMA segment
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ii = 0; ii < 8; ++ii)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[ii], acc[ii][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                OASR_RAW_BARRIER();
             }
         }
+        int64_t m0, n0;
+        tile_origin(i, m0, n0);
+        gemm_epilogue<EPI>(acc, bias, resid, C, N, alpha, m0 + wm * 128, n0 + wn * 64, lane,
+                           smem + 4 * kTileBytes + wave * kEpiSlab);
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[ii][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    if (wm == 0) OASR_RAW_BARRIER();  // same barrier count in both groups
 }
 
 }  // namespace oasr
@@ -154,32 +311,29 @@ extern "C" int oasr_gemm_bf16(const uint16_t* a, const uint16_t* w, const float*
     OASR_REQUIRE(m > 0 && n > 0 && k > 0 && m % BM == 0 && n % BN == 0 && k % BK == 0,
                  "gemm: m=%lld n=%lld must be multiples of 256 and k=%lld of 64", (long long)m,
                  (long long)n, (long long)k);
-    OASR_REQUIRE((m / BM) * (n / BN) < ((int64_t)1 << 31), "gemm: too many tiles");
-    OASR_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)c & 15) == 0,
+    OASR_REQUIRE((m / BM) * (n / BN) < ((int64_t)1 << 30), "gemm: too many tiles");
+    OASR_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)c & 15) == 0 &&
+                     ((uintptr_t)bias & 15) == 0 && ((uintptr_t)resid & 15) == 0,
                  "gemm: operands must be 16-byte aligned");
     OASR_REQUIRE(epilogue != OASR_EPI_RESIDUAL_F32 || resid != nullptr, "gemm: residual epilogue without resid");
-    dim3 grid((unsigned)((m / BM) * (n / BN))), blk(512);
+    const int tiles = (int)((m / BM) * (n / BN));
+    // one persistent work-group per CU; the grid is a multiple of 8 so that every XCD gets the same
+    // number of work-groups
+    dim3 grid((unsigned)(tiles < kMaxCUs ? (tiles + 7) / 8 * 8 : kMaxCUs)), blk(512);
     hipStream_t st = (hipStream_t)stream;
+#define OASR_LAUNCH_GEMM(E) \
+    hipLaunchKernelGGL((gemm_bf16_kernel<E>), grid, blk, 0, st, a, w, bias, resid, c, n, k, alpha, tiles)
     switch (epilogue) {
-        case OASR_EPI_BIAS_BF16:
-            hipLaunchKernelGGL((gemm_bf16_kernel<OASR_EPI_BIAS_BF16>), grid, blk, 0, st, a, w, bias, resid, c, m, n, k, alpha);
-            break;
-        case OASR_EPI_BIAS_SWISH_BF16:
-            hipLaunchKernelGGL((gemm_bf16_kernel<OASR_EPI_BIAS_SWISH_BF16>), grid, blk, 0, st, a, w, bias, resid, c, m, n, k, alpha);
-            break;
-        case OASR_EPI_GLU_BF16:
-            hipLaunchKernelGGL((gemm_bf16_kernel<OASR_EPI_GLU_BF16>), grid, blk, 0, st, a, w, bias, resid, c, m, n, k, alpha);
-            break;
-        case OASR_EPI_RESIDUAL_F32:
-            hipLaunchKernelGGL((gemm_bf16_kernel<OASR_EPI_RESIDUAL_F32>), grid, blk, 0, st, a, w, bias, resid, c, m, n, k, alpha);
-            break;
-        case OASR_EPI_BIAS_F32:
-            hipLaunchKernelGGL((gemm_bf16_kernel<OASR_EPI_BIAS_F32>), grid, blk, 0, st, a, w, bias, resid, c, m, n, k, alpha);
-            break;
+        case OASR_EPI_BIAS_BF16: OASR_LAUNCH_GEMM(OASR_EPI_BIAS_BF16); break;
+        case OASR_EPI_BIAS_SWISH_BF16: OASR_LAUNCH_GEMM(OASR_EPI_BIAS_SWISH_BF16); break;
+        case OASR_EPI_GLU_BF16: OASR_LAUNCH_GEMM(OASR_EPI_GLU_BF16); break;
+        case OASR_EPI_RESIDUAL_F32: OASR_LAUNCH_GEMM(OASR_EPI_RESIDUAL_F32); break;
+        case OASR_EPI_BIAS_F32: OASR_LAUNCH_GEMM(OASR_EPI_BIAS_F32); break;
         default:
             set_error("gemm: unknown epilogue %d", epilogue);
             return OASR_EINVAL;
     }
+#undef OASR_LAUNCH_GEMM
     OASR_CHECK_LAUNCH("gemm");
     return OASR_OK;
 }

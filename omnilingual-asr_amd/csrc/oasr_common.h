@@ -57,8 +57,9 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-__device__ __forceinline__ float swishf(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each): far inside the bf16 tolerance of every consumer
+__device__ __forceinline__ float sigmoidf(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float swishf(float x) { return x * sigmoidf(x); }
 
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
