@@ -10,6 +10,8 @@
 // the B operand of O^T = V^T . P^T (summing over its row index), so P never touches LDS.
 // The relative-key term needs only the L+R+1 distinct values q_i . E[c]: they are computed once per
 // wave by MFMA into LDS; key tiles entirely left (right) of the clamp window use one register value.
+#include <type_traits>
+
 #include "oasr_common.h"
 
 namespace oasr {
@@ -17,8 +19,10 @@ namespace oasr {
 constexpr int kQBlock = 128;   // query rows per work-group (32 per wave)
 constexpr int kKTile = 64;     // keys per iteration
 constexpr int kHead = 64;      // head size
-constexpr int kDistRows = 96;  // rows of the (zero padded) distance-embedding table
-constexpr int kVtPitch = 136;  // bytes per V^T row in LDS: 64 keys * 2 B + 8 B pad (conflict-free b64)
+constexpr int kDistRows = 96;  // rows of the (zero padded) distance-embedding table in global memory
+constexpr int kQeRows = 80;    // rows of q.E kept in LDS (>= left_max + right_max + 1)
+constexpr int kVtPitch = 136;  // bytes per V^T row in LDS: 64 keys * 2 B + 8 B pad (conflict-free b64 reads)
+constexpr float kRescaleThreshold = 6.0f;  // log2 units: the running max is raised only past this
 
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
     typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
@@ -28,25 +32,56 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
     return __builtin_bit_cast(uint32_t, v);
 }
 
+// This file is compiled with -fno-honor-nans (see the Makefile): without it every fmaxf() on an MFMA
+// result gets a canonicalising v_max per operand (3 instructions per max).  Scores are never NaN:
+// masked keys are -inf and the running max is finite from the first tile on.  (Hand-written
+// v_max in inline asm is not an option: hipcc pads no MFMA -> VALU wait states around asm, and the
+// max would read accumulators the matrix pipe has not written yet.)
+__device__ __forceinline__ float vmax(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+// max over the 32 scores a lane holds
+__device__ __forceinline__ float max32(const f32x16& a, const f32x16& b) {
+    float m = vmax(a[0], b[0]);
+#pragma unroll
+    for (int e = 1; e < 16; ++e) m = vmax3(m, a[e], b[e]);
+    return m;
+}
+
+// LDS images, double buffered (one barrier per key tile):
+//   k : [key][64 d] bf16, 128-byte rows; 16-byte chunk c of key r sits at chunk c ^ ((r >> 1) & 7),
+//       which makes the 32-row ds_read_b128 fragment reads conflict-free
+//   vt: [d][key] bf16 (V transposed while staged), rows padded to 136 B; the dword holding keys
+//       (2p, 2p+1) of channel d sits at dword p ^ (((d >> 5) & 1) << 3): fragment reads (b64) stay
+//       conflict-free and the transposing ds_write_b32 of one wave drop from 4-way to 2-way
 struct AttnSmem {
-    __attribute__((aligned(16))) char k[kKTile * 128];          // [key][64 d] bf16, chunk-swizzled
-    __attribute__((aligned(16))) char vt[kHead * kVtPitch];     // [d][key] bf16, padded rows
-    __attribute__((aligned(16))) float qe[4][kDistRows * 32];   // per wave: [c][q] = q . E[c]
+    __attribute__((aligned(16))) char k[2][kKTile * 128];
+    __attribute__((aligned(16))) char vt[2][kHead * kVtPitch];
+    __attribute__((aligned(16))) float qe[4][kQeRows * 32];   // per wave: [c][q] = q . E[c]
 };
 
 __global__ __launch_bounds__(256, 2) void attention_relkey_kernel(
     const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dist_emb,
-    const int32_t* __restrict__ lengths, uint16_t* __restrict__ ctx, int64_t t_pad, int d_model,
-    int left_max, int right_max) {
+    const int32_t* __restrict__ lengths, uint16_t* __restrict__ ctx, int t_pad, int n_heads,
+    int q_blocks, int left_max, int right_max) {
+    const int d_model = n_heads * kHead;
     __shared__ AttnSmem sm;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
-    const int b = blockIdx.z, head = blockIdx.y;
+    // Work item = (utterance, head, query block).  Work-groups with equal blockIdx % 8 share an XCD
+    // (observed round-robin placement; locality only): give each XCD a contiguous run of work items,
+    // query block fastest, so the q-blocks that re-read one (utterance, head)'s K and V hit one L2.
+    int item;
+    {
+        const int nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8;
+        item = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + blockIdx.x / 8;
+    }
+    const int qb = item % q_blocks;
+    const int head = (item / q_blocks) % n_heads, b = item / (q_blocks * n_heads);
     const int len = lengths[b];
-    const int q_blk0 = blockIdx.x * kQBlock;
+    const int q_blk0 = qb * kQBlock;
     if (q_blk0 >= len) return;  // whole block is padding (uniform)
-    const int64_t ld = 3 * (int64_t)d_model;
+    const int ld = 3 * d_model;
     const uint16_t* base = qkv + (int64_t)b * t_pad * ld + head * kHead;
     const int qw0 = q_blk0 + wave * 32;
     const bool wave_active = qw0 < len;
@@ -55,12 +90,12 @@ __global__ __launch_bounds__(256, 2) void attention_relkey_kernel(
     // ---- Q fragments (B operand): lane (r, hh) holds Q[qw0 + r][16 s + 8 hh .. +8], s = 0..3 ---------
     bf16x8 qf[4];
     {
-        const int qrow = min(qw0 + r, (int)t_pad - 1);
-        const uint16_t* qp = base + (int64_t)qrow * ld + 8 * hh;
+        const int qrow = min(qw0 + r, t_pad - 1);
+        const uint16_t* qp = base + qrow * ld + 8 * hh;
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
     }
-    // ---- QE^T[c][q] = E[c] . Q[q]: three 32-row blocks of the distance table -------------------------
+    // ---- QE^T[c][q] = E[c] . Q[q]: 32-row blocks of the distance table ---------------------------------
     float* qe = sm.qe[wave];
     if (wave_active) {
 #pragma unroll
@@ -77,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void attention_relkey_kernel(
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int c = cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                qe[c * 32 + r] = acc[e];
+                if (c < kQeRows) qe[c * 32 + r] = acc[e];
             }
         }
     }
@@ -97,161 +132,201 @@ __global__ __launch_bounds__(256, 2) void attention_relkey_kernel(
     }
     float m_run = -INFINITY, l_run = 0.f;
 
-    // staging roles: K as 2 x 16-byte chunks per thread; V as a key pair x 8 channels per thread
+    // ---- staging roles ------------------------------------------------------------------------------------
+    // K: thread copies 16-byte chunks (key = tid >> 3 (+32), chunk = tid & 7)
+    // V: thread owns key pair kp = tid >> 3 and channels 8 vch .. 8 vch + 7 (vch = tid & 7)
     const int kp = tid >> 3, vch = tid & 7;
     const int n_tiles = (len + kKTile - 1) / kKTile;
+    const int last_row = t_pad - 1;
+    const int k_lds0 = (tid >> 3) * 128 + (((tid & 7) ^ (((tid >> 3) >> 1) & 7)) << 4);
+    const int k_lds1 = (32 + (tid >> 3)) * 128 + (((tid & 7) ^ (((32 + (tid >> 3)) >> 1) & 7)) << 4);
+    const int vt_lds = (vch * 8) * kVtPitch + ((kp ^ (((vch >> 2) & 1) << 3)) << 2);
 
-    uint4 kreg[2], vreg[2];
+    // named registers (not arrays: an array captured by the lambdas below ends up in scratch memory,
+    // which forces a wait right after each global load and defeats the prefetch)
+    uint4 kreg0, kreg1, vreg0, vreg1;
     auto load_tile = [&](int kt) {
         const int k0 = kt * kKTile;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int ci = tid + 256 * i;
-            const int key = min(k0 + (ci >> 3), (int)t_pad - 1);
-            kreg[i] = *reinterpret_cast<const uint4*>(base + (int64_t)key * ld + d_model + (ci & 7) * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int key = k0 + 2 * kp + i;
-            const int krow = min(key, (int)t_pad - 1);
-            uint4 v = *reinterpret_cast<const uint4*>(base + (int64_t)krow * ld + 2 * d_model + vch * 8);
-            if (key >= len) v = make_uint4(0, 0, 0, 0);  // masked keys must not inject non-finite values
-            vreg[i] = v;
-        }
+        const uint16_t* kb = base + d_model + (tid & 7) * 8;
+        kreg0 = *reinterpret_cast<const uint4*>(kb + min(k0 + (tid >> 3), last_row) * ld);
+        kreg1 = *reinterpret_cast<const uint4*>(kb + min(k0 + 32 + (tid >> 3), last_row) * ld);
+        const uint16_t* vb = base + 2 * d_model + vch * 8;
+        const int key = k0 + 2 * kp;
+        vreg0 = *reinterpret_cast<const uint4*>(vb + min(key, last_row) * ld);
+        vreg1 = *reinterpret_cast<const uint4*>(vb + min(key + 1, last_row) * ld);
+        // masked keys must not inject non-finite values
+        if (key >= len) vreg0 = make_uint4(0, 0, 0, 0);
+        if (key + 1 >= len) vreg1 = make_uint4(0, 0, 0, 0);
     };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int ci = tid + 256 * i;
-            const int key = ci >> 3, ch = ci & 7;
-            *reinterpret_cast<uint4*>(sm.k + key * 128 + ((ch ^ (key & 7)) << 4)) = kreg[i];
-        }
-        const uint32_t a[4] = {vreg[0].x, vreg[0].y, vreg[0].z, vreg[0].w};
-        const uint32_t c[4] = {vreg[1].x, vreg[1].y, vreg[1].z, vreg[1].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            // channels 8 vch + 2e and + 2e + 1, keys 2 kp and 2 kp + 1 packed into one dword each
-            const uint32_t lo = (a[e] & 0xFFFFu) | (c[e] << 16);
-            const uint32_t hi = (a[e] >> 16) | (c[e] & 0xFFFF0000u);
-            *reinterpret_cast<uint32_t*>(sm.vt + (vch * 8 + 2 * e) * kVtPitch + kp * 4) = lo;
-            *reinterpret_cast<uint32_t*>(sm.vt + (vch * 8 + 2 * e + 1) * kVtPitch + kp * 4) = hi;
-        }
+    auto store_tile = [&](int buf) {
+        *reinterpret_cast<uint4*>(sm.k[buf] + k_lds0) = kreg0;
+        *reinterpret_cast<uint4*>(sm.k[buf] + k_lds1) = kreg1;
+        char* vt = sm.vt[buf] + vt_lds;
+        // channels 8 vch + 2e and + 2e + 1; keys 2 kp and 2 kp + 1 packed into one dword each
+#define OASR_VT_PAIR(E, A, C)                                                                              \
+        *reinterpret_cast<uint32_t*>(vt + (2 * (E)) * kVtPitch) = __builtin_amdgcn_perm((C), (A), 0x05040100); \
+        *reinterpret_cast<uint32_t*>(vt + (2 * (E) + 1) * kVtPitch) = __builtin_amdgcn_perm((C), (A), 0x07060302);
+        OASR_VT_PAIR(0, vreg0.x, vreg1.x)
+        OASR_VT_PAIR(1, vreg0.y, vreg1.y)
+        OASR_VT_PAIR(2, vreg0.z, vreg1.z)
+        OASR_VT_PAIR(3, vreg0.w, vreg1.w)
+#undef OASR_VT_PAIR
     };
+
+    // K fragment addresses: lane (r, hh) reads key r (+32), logical chunk 2 s + hh
+    int k_frag[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) k_frag[s] = r * 128 + (((2 * s + hh) ^ ((r >> 1) & 7)) << 4);
+    // (32 + r) >> 1 = 16 + (r >> 1): same low three bits, so the second half only adds 32 rows
+    // V^T fragment address of row r (+32): dword 16 u + 8 s2 + 2 hh (+4), swizzled by the row block
+    constexpr int vt_sw0 = 0, vt_sw1 = 8;   // ((row >> 5) & 1) << 3 for rows r and 32 + r
 
     load_tile(0);
-    for (int kt = 0; kt < n_tiles; ++kt) {
-        __syncthreads();  // previous tile's LDS reads are done
-        store_tile();
-        __syncthreads();
-        if (kt + 1 < n_tiles) load_tile(kt + 1);  // in flight during the MFMA work below
-        if (!wave_active) continue;
-        const int k0 = kt * kKTile;
+    store_tile(0);
+    if (n_tiles > 1) load_tile(1);
+    __syncthreads();
 
-        // ---- S^T = K . Q^T for the two 32-key halves ----------------------------------------------------
-        f32x16 s0, s1;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            s0[e] = 0.f;
-            s1[e] = 0.f;
+    // One key tile.  FAR: every (query, key) distance of this wave's rows lies outside the clamp
+    // window on one side and no key is masked, so the relative-key term is one value per lane.  The
+    // two cases are separate loops below (not a flag inside one loop) so that the far path does not
+    // carry the per-element table gather and masking of the general path.
+    auto process_tile = [&](auto far_c, int kt, float bias) {
+        constexpr bool FAR = decltype(far_c)::value;
+        const int buf = kt & 1;
+        // stage tile kt+1 (already in registers) into the other buffer, then request tile kt+2
+#ifndef OASR_ABL
+#define OASR_ABL 0
+#endif
+        if (kt + 1 < n_tiles) {
+            if (!(OASR_ABL & 2)) store_tile(buf ^ 1);
+            if (kt + 2 < n_tiles && !(OASR_ABL & 1)) load_tile(kt + 2);
         }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int chunk = (2 * s + hh) ^ (r & 7);
-            const bf16x8 ka = *reinterpret_cast<const bf16x8*>(sm.k + r * 128 + (chunk << 4));
-            const bf16x8 kb = *reinterpret_cast<const bf16x8*>(sm.k + (32 + r) * 128 + (chunk << 4));
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb, qf[s], s1, 0, 0, 0);
-        }
-        // ---- scale, relative-key bias, mask ----------------------------------------------------------------
-        const int q = qw0 + r;
-        const int dmax = k0 + kKTile - 1 - qw0, dmin = k0 - (qw0 + 31);  // wave-uniform distance range
-        if (dmax <= -left_max) {
+        if (wave_active) {
+            const int k0 = kt * kKTile;
+            const char* kbuf = sm.k[buf];
+            const char* vbuf = sm.vt[buf];
+            // ---- S^T = K . Q^T for the two 32-key halves ------------------------------------------------
+            f32x16 s0, s1;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                s0[e] = s0[e] * cs + bias_left;
-                s1[e] = s1[e] * cs + bias_left;
+                s0[e] = 0.f;
+                s1[e] = 0.f;
             }
-        } else if (dmin >= right_max) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                s0[e] = s0[e] * cs + bias_right;
-                s1[e] = s1[e] * cs + bias_right;
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 ka = *reinterpret_cast<const bf16x8*>(kbuf + k_frag[s]);
+                const bf16x8 kb = *reinterpret_cast<const bf16x8*>(kbuf + 32 * 128 + k_frag[s]);
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb, qf[s], s1, 0, 0, 0);
             }
-        } else {
+            // ---- log2-domain scores t = s * cs + bias; softmax with a lazily raised running max ------------
+            float psum = 0.f;
+            if (FAR) {
+                float tmax = max32(s0, s1) * cs + bias;
+                tmax = vmax(tmax, __shfl_xor(tmax, 32, 64));
+                // both lanes of a query (r, r + 32) see the same tmax and m_run: same decision
+                const float m_new = tmax > m_run + kRescaleThreshold ? tmax : m_run;
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // 1 when unchanged
+                m_run = m_new;
+                l_run *= alpha;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                const int c0 = min(max(key - q, -left_max), right_max) + left_max;
-                const int c1 = min(max(key + 32 - q, -left_max), right_max) + left_max;
-                s0[e] = (s0[e] + qe[c0 * 32 + r]) * cs;
-                s1[e] = (s1[e] + qe[c1 * 32 + r]) * cs;
+                for (int e = 0; e < 16; ++e) {
+                    o0[e] *= alpha;
+                    o1[e] *= alpha;
+                }
+                const float off = bias - m_run;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if (!(OASR_ABL & 8)) {
+                    s0[e] = __builtin_amdgcn_exp2f(fmaf(s0[e], cs, off));
+                    s1[e] = __builtin_amdgcn_exp2f(fmaf(s1[e], cs, off));
+                    }
+                    psum += s0[e] + s1[e];
+                }
+            } else {
+                const int q = qw0 + r;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    const int c0 = min(max(key - q, -left_max), right_max) + left_max;
+                    const int c1 = min(max(key + 32 - q, -left_max), right_max) + left_max;
+                    s0[e] = key < len ? (s0[e] + qe[c0 * 32 + r]) * cs : -INFINITY;
+                    s1[e] = key + 32 < len ? (s1[e] + qe[c1 * 32 + r]) * cs : -INFINITY;
+                }
+                float tmax = max32(s0, s1);
+                tmax = vmax(tmax, __shfl_xor(tmax, 32, 64));
+                const float m_new = tmax > m_run + kRescaleThreshold ? tmax : m_run;
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    o0[e] *= alpha;
+                    o1[e] *= alpha;
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    s0[e] = __builtin_amdgcn_exp2f(s0[e] - m_run);
+                    s1[e] = __builtin_amdgcn_exp2f(s1[e] - m_run);
+                    psum += s0[e] + s1[e];
+                }
             }
-        }
-        if (k0 + kKTile > len) {
+            l_run += psum;
+            // ---- O^T += V^T . P^T ---------------------------------------------------------------------------
+            // k-step (u, s2): P fragment = registers 8 s2 .. 8 s2 + 7 of S_u; its element j is key
+            // 32 u + 16 s2 + 8 (j >> 2) + 4 hh + (j & 3), so V^T is read as two 8-byte pieces.
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                if (key >= len) s0[e] = -INFINITY;
-                if (key + 32 >= len) s1[e] = -INFINITY;
-            }
-        }
-        // ---- online softmax (base 2) -----------------------------------------------------------------------
-        float tmax = fmaxf(s0[0], s1[0]);
+            for (int u = 0; u < 2; ++u) {
 #pragma unroll
-        for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, fmaxf(s0[e], s1[e]));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        float psum = 0.f;
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const f32x16& sv = u ? s1 : s0;
+                    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+                    u32x4 pw;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            s0[e] = __builtin_amdgcn_exp2f(s0[e] - m_new);
-            s1[e] = __builtin_amdgcn_exp2f(s1[e] - m_new);
-            psum += s0[e] + s1[e];
-        }
-        l_run = l_run * alpha + psum;
+                    for (int j = 0; j < 4; ++j) pw[j] = cvt_pk_bf16(sv[8 * s2 + 2 * j], sv[8 * s2 + 2 * j + 1]);
+                    const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+                    const int dw = 16 * u + 8 * s2 + 2 * hh;   // dword index of the first piece
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            o0[e] *= alpha;
-            o1[e] *= alpha;
-        }
-        // ---- O^T += V^T . P^T ---------------------------------------------------------------------------------
-        // k-step (u, s2): P fragment = registers 8 s2 .. 8 s2 + 7 of S_u; its element j is key
-        // 32 u + 16 s2 + 8 (j >> 2) + 4 hh + (j & 3), so V^T is read as two 8-byte pieces.
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const f32x16& sv = u ? s1 : s0;
-                typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-                u32x4 pw;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) pw[j] = cvt_pk_bf16(sv[8 * s2 + 2 * j], sv[8 * s2 + 2 * j + 1]);
-                const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
-                const int koff = (32 * u + 16 * s2 + 4 * hh) * 2;
-#pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    const char* vp = sm.vt + (32 * db + r) * kVtPitch + koff;
-                    const uint2 va = *reinterpret_cast<const uint2*>(vp);
-                    const uint2 vb = *reinterpret_cast<const uint2*>(vp + 16);
-                    u32x4 vw = {va.x, va.y, vb.x, vb.y};
-                    const bf16x8 vf = __builtin_bit_cast(bf16x8, vw);
-                    if (db == 0)
-                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o0, 0, 0, 0);
-                    else
-                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o1, 0, 0, 0);
+                    for (int db = 0; db < 2; ++db) {
+                        const char* vp = vbuf + (32 * db + r) * kVtPitch;
+                        const int sw = db ? vt_sw1 : vt_sw0;
+                        const uint2 va = *reinterpret_cast<const uint2*>(vp + ((dw ^ sw) << 2));
+                        const uint2 vb = *reinterpret_cast<const uint2*>(vp + (((dw + 4) ^ sw) << 2));
+                        u32x4 vw = {va.x, va.y, vb.x, vb.y};
+                        const bf16x8 vf = __builtin_bit_cast(bf16x8, vw);
+                        if (db == 0)
+                            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o0, 0, 0, 0);
+                        else
+                            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o1, 0, 0, 0);
+                    }
                 }
             }
         }
-    }
+        if (!(OASR_ABL & 4)) __syncthreads();  // tile kt+1 is staged; everyone is done reading buffer kt & 1
+    };
+
+    // Tile ranges of this wave (wave-uniform; every wave still runs n_tiles tiles = n_tiles barriers):
+    //   [0, n_left)        all distances <= -left_max        -> FAR with the left-edge bias
+    //   [n_left, first_r)  inside the clamp window           -> general
+    //   [first_r, n_full)  all distances >= right_max        -> FAR with the right-edge bias
+    //   [n_full, n_tiles)  the last tile when it has masked keys -> general
+    const int n_full = len / kKTile;   // tiles without masked keys
+    int n_left = (qw0 - (kKTile - 1) - left_max >= 0) ? (qw0 - (kKTile - 1) - left_max) / kKTile + 1 : 0;
+    int first_r = (qw0 + 31 + right_max + kKTile - 1) / kKTile;
+    n_left = min(n_left, n_full);
+    first_r = min(max(first_r, n_left), n_full);
+    int kt = 0;
+    for (; kt < n_left; ++kt) process_tile(std::true_type{}, kt, bias_left);
+    for (; kt < first_r; ++kt) process_tile(std::false_type{}, kt, 0.f);
+    for (; kt < n_full; ++kt) process_tile(std::true_type{}, kt, bias_right);
+    for (; kt < n_tiles; ++kt) process_tile(std::false_type{}, kt, 0.f);
 
     if (!wave_active) return;
     // ---- normalise and store: lane holds ctx[q][32 db + 8 g + 4 hh + {0..3}] ---------------------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     const int q = qw0 + r;
-    if (q < (int)t_pad) {
+    if (q < t_pad) {
         uint16_t* op = ctx + ((int64_t)b * t_pad + q) * d_model + head * kHead + 4 * hh;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -276,11 +351,15 @@ extern "C" int oasr_attention_relkey(const uint16_t* qkv, const uint16_t* dist_e
     OASR_REQUIRE(qkv && dist_emb && lengths && ctx, "attention: null pointer");
     OASR_REQUIRE(batch > 0 && batch <= 65535 && n_heads > 0 && n_heads <= 65535, "attention: bad batch/heads");
     OASR_REQUIRE(t_pad > 0 && t_pad % 32 == 0, "attention: t_pad must be a positive multiple of 32");
-    OASR_REQUIRE(left_max >= 0 && right_max >= 0 && left_max + right_max + 1 <= kDistRows,
-                 "attention: left_max + right_max + 1 must be <= %d", kDistRows);
-    dim3 grid((unsigned)((t_pad + kQBlock - 1) / kQBlock), (unsigned)n_heads, (unsigned)batch);
+    OASR_REQUIRE(left_max >= 0 && right_max >= 0 && left_max + right_max + 1 <= kQeRows,
+                 "attention: left_max + right_max + 1 must be <= %d", kQeRows);
+    OASR_REQUIRE((int64_t)batch * t_pad * 3 * n_heads * kHead < ((int64_t)1 << 31),
+                 "attention: qkv matrix too large for 32-bit element offsets");
+    const int q_blocks = (int)((t_pad + kQBlock - 1) / kQBlock);
+    OASR_REQUIRE((int64_t)q_blocks * n_heads * batch < ((int64_t)1 << 31), "attention: too many work items");
+    dim3 grid((unsigned)(q_blocks * n_heads * batch));
     hipLaunchKernelGGL(attention_relkey_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv,
-                       dist_emb, lengths, ctx, t_pad, n_heads * kHead, left_max, right_max);
+                       dist_emb, lengths, ctx, (int)t_pad, n_heads, q_blocks, left_max, right_max);
     OASR_CHECK_LAUNCH("attention");
     return OASR_OK;
 }
