@@ -60,7 +60,7 @@ int build_logmel_blob(uint32_t* blob) {
     const int nb = OASR_NFFT / 2 + 1;
     std::vector<double> dense((size_t)nb * OASR_NMEL);
     build_mel_dense(dense.data());
-    int off = 0;
+    int widest = 0;
     for (int j = 0; j < OASR_NMEL; ++j) {
         int first = -1, last = -1;
         for (int k = 0; k < nb; ++k)
@@ -73,13 +73,13 @@ int build_logmel_blob(uint32_t* blob) {
             last = -1;
         }
         const int cnt = last - first + 1;
-        if (off + cnt > kMelNnzCap) return -1;
+        if (cnt > kMelWidth) return -1;
+        if (cnt > widest) widest = cnt;
         b->mel_start[j] = first;
-        b->mel_count[j] = cnt;
-        b->mel_offset[j] = off;
-        for (int i = 0; i < cnt; ++i) b->mel_w[off + i] = (float)dense[(first + i) * OASR_NMEL + j];
-        off += cnt;
+        for (int i = 0; i < cnt; ++i) b->mel_w[j * kMelWidth + i] = (float)dense[(first + i) * OASR_NMEL + j];
     }
+    b->mel_start[OASR_NMEL] = 0;
+    b->mel_width_max = widest;
     return 0;
 }
 

@@ -17,7 +17,9 @@ constexpr int kWaves = 4;
 constexpr int kSpan = (kFramesPerBlock - 1) * OASR_FRAME_HOP + OASR_FRAME_LEN;  // 5360 samples
 constexpr float kMelFloor = 1.192092955078125e-07f;
 constexpr float kNormEps = 1e-7f;
-constexpr float kPcmScale = 32768.0f;  // Kaldi convention: 16-bit integer range
+constexpr float kPcmScale = 32768.0f;
+constexpr int kMelPitch = kMelWidth + 1;       // odd pitch: lanes reading column i of 64 rows hit distinct banks
+constexpr int kPPitch = 257 + kMelWidth + 3;   // room for a padded triangle starting at the last bin  // Kaldi convention: 16-bit integer range
 
 // Orders this wave's LDS writes before its later LDS reads (DS operations of one wave execute in
 // order; this only pins the compiler).
@@ -65,7 +67,8 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
                                                      int64_t stats_slots) {
     __shared__ __attribute__((aligned(16))) float span[kSpan + 8];
     __shared__ __attribute__((aligned(16))) float2 zbuf[kWaves][256];
-    __shared__ float pbuf[kWaves][264];
+    __shared__ float pbuf[kWaves][kPPitch];            // power spectrum; entries >= 257 stay zero
+    __shared__ float melw[81 * kMelPitch];             // padded triangle weights (block copy, odd row pitch)
     __shared__ float wstat[kWaves][OASR_NMEL][2];
 
     const int b = blockIdx.y;
@@ -99,6 +102,9 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
         }
     }
 
+    for (int i = tid; i < 81 * kMelWidth; i += 256) melw[(i / kMelWidth) * kMelPitch + i % kMelWidth] = tab->mel_w[i];
+    for (int i = tid; i < kWaves * kPPitch; i += 256) (&pbuf[0][0])[i] = 0.0f;
+
     // ---- per-lane constants ------------------------------------------------------------------------
     // lane holds complex points n = lane + 64 j (j = 0..3), i.e. samples 2n and 2n+1 of the frame
     float w_even[4], w_odd[4];
@@ -118,11 +124,13 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
 #pragma unroll
     for (int m = 0; m < 4; ++m) twp[m] = tw512(tab, lane + 64 * m);
 
-    // mel filters owned by this lane: j = lane, and j = 64 + lane for lane < 16
-    const int mj0 = lane, mj1 = 64 + (lane & 15);
-    const int ms0 = tab->mel_start[mj0], mc0 = tab->mel_count[mj0], mo0 = tab->mel_offset[mj0];
-    const int ms1 = tab->mel_start[mj1], mc1 = lane < 16 ? tab->mel_count[mj1] : 0,
-              mo1 = tab->mel_offset[mj1];
+    // mel triangles owned by this lane: A = lane, and B = 79 - lane for lane < 16 (the widest
+    // triangles are paired with the narrowest; other lanes point B at the all-zero dummy row 80).
+    // Weights are zero padded to kMelWidth bins, so the sum below is a fixed-length, branch-free loop.
+    const int mjA = lane, mjB = lane < 16 ? 79 - lane : 80;
+    const float* wA = melw + mjA * kMelPitch;
+    const float* wB = melw + mjB * kMelPitch;
+    const int msA = tab->mel_start[mjA], msB = tab->mel_start[mjB];
 
     float2* z = zbuf[wave];
     float* p = pbuf[wave];
@@ -222,14 +230,17 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
         OASR_WAVE_SYNC();
         // ---- mel triangles, floor, log --------------------------------------------------------------
         float m0 = 0.f, m1 = 0.f;
-        for (int i = 0; i < mc0; ++i) m0 += tab->mel_w[mo0 + i] * p[ms0 + i];
-        for (int i = 0; i < mc1; ++i) m1 += tab->mel_w[mo1 + i] * p[ms1 + i];
+#pragma unroll
+        for (int i = 0; i < kMelWidth; ++i) {
+            m0 = fmaf(wA[i], p[msA + i], m0);
+            m1 = fmaf(wB[i], p[msB + i], m1);
+        }
         const float l0 = logf(fmaxf(m0, kMelFloor));
         const float l1 = logf(fmaxf(m1, kMelFloor));
         OASR_WAVE_SYNC();  // p and z are rewritten by the next frame
         float* dst = out + ((int64_t)b * frame_cap + (f0 + fi)) * OASR_NMEL;
         dst[lane] = l0;
-        if (lane < 16) dst[64 + lane] = l1;
+        if (lane < 16) dst[79 - lane] = l1;
         if (nw == 0) {
             c0 = l0;
             c1 = l1;
@@ -249,8 +260,8 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
         wstat[wave][lane][0] = c0 + s1_0 * inv;
         wstat[wave][lane][1] = fmaxf(s2_0 - s1_0 * s1_0 * inv, 0.0f);
         if (lane < 16) {
-            wstat[wave][64 + lane][0] = c1 + s1_1 * inv;
-            wstat[wave][64 + lane][1] = fmaxf(s2_1 - s1_1 * s1_1 * inv, 0.0f);
+            wstat[wave][79 - lane][0] = c1 + s1_1 * inv;
+            wstat[wave][79 - lane][1] = fmaxf(s2_1 - s1_1 * s1_1 * inv, 0.0f);
         }
     }
     __syncthreads();
@@ -275,34 +286,40 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ p
 }
 
 // One work-group per utterance: merge the per-block partials (Chan's pairwise update, in double)
-// into (mean, 1/sqrt(var_ddof1 + eps)) kept in the last stats slot.
-__global__ __launch_bounds__(128) void stats_finalize_kernel(float* __restrict__ stats,
-                                                             int64_t stats_slots,
-                                                             const int32_t* __restrict__ n_samples,
-                                                             int64_t frame_cap) {
-    const int b = blockIdx.x, j = threadIdx.x;
-    if (j >= OASR_NMEL) return;
+// into (mean, 1/sqrt(var_ddof1 + eps)) kept in the last stats slot.  Eight lanes share a mel bin and
+// each sums every eighth slot, so the dependent chain of strided loads is 8x shorter.
+constexpr int kFinalizeLanes = 8;
+__global__ __launch_bounds__(OASR_NMEL * kFinalizeLanes) void stats_finalize_kernel(
+    float* __restrict__ stats, int64_t stats_slots, const int32_t* __restrict__ n_samples,
+    int64_t frame_cap) {
+    const int b = blockIdx.x, j = threadIdx.x / kFinalizeLanes, part = threadIdx.x % kFinalizeLanes;
     const int ns = n_samples[b];
     int nf = ns < OASR_FRAME_LEN ? 0 : 1 + (ns - OASR_FRAME_LEN) / OASR_FRAME_HOP;
     if (nf > (int)frame_cap) nf = (int)frame_cap;
     float* base = stats + (int64_t)b * stats_slots * (OASR_NMEL * 2);
     const int nblk = (nf + kFramesPerBlock - 1) / kFramesPerBlock;
     double sum = 0.0;
-    for (int s = 0; s < nblk; ++s) {
+    for (int s = part; s < nblk; s += kFinalizeLanes) {
         const int cnt = min(kFramesPerBlock, nf - s * kFramesPerBlock);
         sum += (double)cnt * (double)base[(s * OASR_NMEL + j) * 2];
     }
+#pragma unroll
+    for (int o = 1; o < kFinalizeLanes; o <<= 1) sum += __shfl_xor(sum, o, 64);
     const double mean = nf > 0 ? sum / nf : 0.0;
     double m2 = 0.0;
-    for (int s = 0; s < nblk; ++s) {
+    for (int s = part; s < nblk; s += kFinalizeLanes) {
         const int cnt = min(kFramesPerBlock, nf - s * kFramesPerBlock);
         const double dm = (double)base[(s * OASR_NMEL + j) * 2] - mean;
         m2 += (double)base[(s * OASR_NMEL + j) * 2 + 1] + cnt * dm * dm;
     }
-    const double var = nf > 1 ? m2 / (nf - 1) : 0.0;
-    float* fin = base + (stats_slots - 1) * (OASR_NMEL * 2);
-    fin[j * 2 + 0] = (float)mean;
-    fin[j * 2 + 1] = (float)(1.0 / sqrt(var + (double)kNormEps));
+#pragma unroll
+    for (int o = 1; o < kFinalizeLanes; o <<= 1) m2 += __shfl_xor(m2, o, 64);
+    if (part == 0) {
+        const double var = nf > 1 ? m2 / (nf - 1) : 0.0;
+        float* fin = base + (stats_slots - 1) * (OASR_NMEL * 2);
+        fin[j * 2 + 0] = (float)mean;
+        fin[j * 2 + 1] = (float)(1.0 / sqrt(var + (double)kNormEps));
+    }
 }
 
 // Normalise and stack: the [frames][80] log-mel rows of an utterance are contiguous, so a stacked
@@ -370,7 +387,7 @@ int oasr_feature_norm_stack(const float* logmel, float* stats, const int32_t* n_
     OASR_REQUIRE(batch > 0 && batch <= 65535, "norm_stack: batch %d out of range", batch);
     OASR_REQUIRE(t_pad > 0 && 2 * t_pad <= frame_cap, "norm_stack: need 2*t_pad <= frame_cap");
     const int64_t slots = oasr_logmel_stats_slots(frame_cap);
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)batch), dim3(128), 0,
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)batch), dim3(OASR_NMEL * kFinalizeLanes), 0,
                        (hipStream_t)stream, stats, slots, n_samples, frame_cap);
     OASR_CHECK_LAUNCH("stats_finalize");
     const int64_t vec = t_pad * OASR_FEAT_DIM / 4;

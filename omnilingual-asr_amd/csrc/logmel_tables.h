@@ -5,16 +5,16 @@
 
 namespace oasr {
 
-constexpr int kMelNnzCap = 640;  // non-zero triangle weights over all 80 filters (actual: ~510)
+constexpr int kMelWidth = 20;    // padded number of FFT bins per mel triangle (widest real one: 18)
 
 struct LogmelBlob {
     float window[400];       // Povey window
     float tw_re[256];        // cos(2 pi k / 512)
     float tw_im[256];        // -sin(2 pi k / 512)
-    int32_t mel_start[80];   // first FFT bin with non-zero weight
-    int32_t mel_count[80];   // number of consecutive bins
-    int32_t mel_offset[80];  // offset of the filter's weights in mel_w
-    float mel_w[kMelNnzCap];
+    int32_t mel_start[81];            // first FFT bin of each triangle; entry 80 is a dummy (bin 0)
+    int32_t mel_width_max;            // widest triangle, in bins (checked against kMelWidth)
+    int32_t pad_[2];
+    float mel_w[81 * kMelWidth];      // [filter][kMelWidth] weights, zero padded; row 80 is all zeros
 };
 
 int build_logmel_blob(uint32_t* blob);
