@@ -216,14 +216,23 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(const uint16_t* __restri
     const int tiles_n = (int)(N / BN);
 
     // Tile list of this work-group.  Work-groups with equal blockIdx % 8 share an XCD (observed
-    // round-robin placement; used for L2 locality only, never for correctness): XCD x owns the
-    // contiguous tile range [x*n_tiles/8, (x+1)*n_tiles/8) and its work-groups interleave over it,
-    // so the tiles in flight on one XCD at any time are consecutive ones (n fastest) that share A
-    // and W panels.
+    // round-robin placement; used for L2 locality only, never for correctness).  XCD x owns a
+    // contiguous range of m-tiles (all n).  Inside it tiles are ordered band by band, a band being
+    // `band_w` (<= 4) n-tiles wide, m running fastest after n: the ~32 tiles in flight on an XCD are
+    // then ~8 m-tiles x 4 n-tiles, whose W rows (4 x 256 x K) stay in the 4 MiB L2 for the whole
+    // band while each A panel is fetched once per band.  (With n running over all of N, every
+    // round of 32 tiles re-streamed the whole weight matrix: 0.93 GB fetched per 48128x4096x1024
+    // launch against 0.11 GB of operands.)
+    // Small problems (fewer than 2 m-tiles per XCD) split the flat tile list evenly instead.
+    const int tiles_m = n_tiles / tiles_n;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
-    const int t_lo = (int)((int64_t)n_tiles * xcd / 8), t_hi = (int)((int64_t)n_tiles * (xcd + 1) / 8);
-    if (t_lo + slot >= t_hi) return;
-    const int my_tiles = (t_hi - t_lo - slot + per_xcd - 1) / per_xcd;  // tiles t_lo + slot + i*per_xcd
+    const bool banded = tiles_m >= 16;
+    const int m_lo = (int)((int64_t)tiles_m * xcd / 8), m_cnt = (int)((int64_t)tiles_m * (xcd + 1) / 8) - m_lo;
+    const int band_w = tiles_n % 4 == 0 ? 4 : (tiles_n % 3 == 0 ? 3 : (tiles_n % 2 == 0 ? 2 : 1));
+    const int flat_lo = (int)((int64_t)n_tiles * xcd / 8);
+    const int local_tiles = banded ? m_cnt * tiles_n : (int)((int64_t)n_tiles * (xcd + 1) / 8) - flat_lo;
+    if (slot >= local_tiles) return;
+    const int my_tiles = (local_tiles - slot + per_xcd - 1) / per_xcd;  // local tiles slot + i*per_xcd
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -239,9 +248,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(const uint16_t* __restri
     const int total = my_tiles * nt;
 
     auto tile_origin = [&](int i, int64_t& m0, int64_t& n0) {
-        const int tile = t_lo + slot + i * per_xcd;
-        m0 = (int64_t)(tile / tiles_n) * BM;
-        n0 = (int64_t)(tile % tiles_n) * BN;
+        const int l = slot + i * per_xcd;
+        if (banded) {
+            const int band = l / (m_cnt * band_w), in_band = l % (m_cnt * band_w);
+            m0 = (int64_t)(m_lo + in_band / band_w) * BM;
+            n0 = (int64_t)(band * band_w + in_band % band_w) * BN;
+        } else {
+            m0 = (int64_t)((flat_lo + l) / tiles_n) * BM;
+            n0 = (int64_t)((flat_lo + l) % tiles_n) * BN;
+        }
     };
     auto stage_step = [&](int g) {  // global step g = i * nt + t  ->  buffer g & 1
         int64_t m0, n0;
