@@ -194,12 +194,9 @@ __global__ __launch_bounds__(256, 2) void attention_relkey_kernel(
         constexpr bool FAR = decltype(far_c)::value;
         const int buf = kt & 1;
         // stage tile kt+1 (already in registers) into the other buffer, then request tile kt+2
-#ifndef OASR_ABL
-#define OASR_ABL 0
-#endif
         if (kt + 1 < n_tiles) {
-            if (!(OASR_ABL & 2)) store_tile(buf ^ 1);
-            if (kt + 2 < n_tiles && !(OASR_ABL & 1)) load_tile(kt + 2);
+            store_tile(buf ^ 1);
+            if (kt + 2 < n_tiles) load_tile(kt + 2);
         }
         if (wave_active) {
             const int k0 = kt * kKTile;
@@ -237,10 +234,8 @@ __global__ __launch_bounds__(256, 2) void attention_relkey_kernel(
                 const float off = bias - m_run;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    if (!(OASR_ABL & 8)) {
                     s0[e] = __builtin_amdgcn_exp2f(fmaf(s0[e], cs, off));
                     s1[e] = __builtin_amdgcn_exp2f(fmaf(s1[e], cs, off));
-                    }
                     psum += s0[e] + s1[e];
                 }
             } else {
@@ -302,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void attention_relkey_kernel(
                 }
             }
         }
-        if (!(OASR_ABL & 4)) __syncthreads();  // tile kt+1 is staged; everyone is done reading buffer kt & 1
+        __syncthreads();  // tile kt+1 is staged; everyone is done reading buffer kt & 1
     };
 
     // Tile ranges of this wave (wave-uniform; every wave still runs n_tiles tiles = n_tiles barriers):

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Turn the profiler output of tools/profile_round.sh (gpurun_out/<tag>_*) into the files kept under
+profiles/: <tag>_kernel_stats_{graph,eager}.csv, <tag>_summary.md and <tag>_traffic.json."""
+import csv
+import glob
+import json
+import shutil
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+out = ROOT / "gpurun_out"
+prof = ROOT / "profiles"
+prof.mkdir(exist_ok=True)
+
+
+def one(pattern):
+    hits = glob.glob(str(out / pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+def stats_table(mode):
+    f = one("%s_stats_%s/**/*kernel_stats.csv" % (tag, mode))
+    if not f:
+        return None, None
+    shutil.copy(f, prof / ("%s_kernel_stats_%s.csv" % (tag, mode)))
+    rows = list(csv.DictReader(open(f)))
+    lines = ["| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
+    for r in rows:
+        lines.append("| `%s` | %s | %.3f | %.2f | %s |" % (r["Name"][:110], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                       float(r["AverageNs"]) / 1e3, r["Percentage"]))
+    return "\n".join(lines), rows
+
+
+def counter(kind, name, kernel_substr):
+    f = one("%s_pmc_%s_%s/**/*counter_collection.csv" % (tag, kind, name))
+    if not f:
+        return None
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
+            if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == name]
+    vals.sort()
+    return vals[len(vals) // 2] if vals else None
+
+
+md = ["# %s - rocprofv3 evidence (MI355X, batch 32 x 30 s, G300)" % tag, ""]
+for mode, cmd in (("graph", "python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline"),
+                  ("eager", "python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-graph")):
+    table, _ = stats_table(mode)
+    if table:
+        log = out / ("%s_stats_%s.log" % (tag, mode))
+        last = [l for l in log.read_text().splitlines() if l.startswith("{")]
+        md += ["## `rocprofv3 --kernel-trace --stats -- %s`" % cmd, "",
+               "13 forwards (3 warm-up + 10 timed) plus the 21 event-timed launches each of the FFN up-projection GEMM",
+               "and the log-mel kernel that bench.py issues for its roofline lines.", "", table, ""]
+        if last:
+            md += ["bench line of this run:", "", "```", last[-1], "```", ""]
+
+traffic = {}
+KB = 1024.0
+for kind, substr, key, shape, algo in (
+        ("gemm", "gemm_bf16_kernel<1>", "gemm_bf16_kernel<1>", "48128x4096x1024",
+         48128 * 1024 * 2 + 4096 * 1024 * 2 + 4096 * 4 + 48128 * 4096 * 2),
+        ("logmel", "logmel_kernel", "logmel_kernel", "32x480000", 32 * (480000 * 4 + 2998 * 80 * 4))):
+    fetch = counter(kind, "FETCH_SIZE", substr)
+    write = counter(kind, "WRITE_SIZE", substr)
+    if fetch is None or write is None:
+        continue
+    # rocprofv3 reports both in KiB; on gfx950 FETCH_SIZE tallies each 128-byte request of a wide
+    # streaming read as 64 bytes, so it is doubled; WRITE_SIZE is exact for 16-byte-per-lane stores.
+    traffic[key] = {"shape": shape, "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB_raw": write,
+                    "fetch_bytes_corrected": fetch * KB * 2, "write_bytes": write * KB,
+                    "traffic_bytes_per_launch": fetch * KB * 2 + write * KB,
+                    "algorithmic_bytes_per_launch": algo}
+(prof / ("%s_traffic.json" % tag)).write_text(json.dumps(traffic, indent=1) + "\n")
+md += ["## HBM-side bytes per launch (`rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separate runs)", "",
+       "FETCH_SIZE doubled (gfx950 counts a 128-byte request as 64 bytes); Infinity-Cache hits are included.", "",
+       "| kernel | shape | FETCH raw KiB | WRITE raw KiB | traffic MB | algorithmic MB |", "|---|---|---|---|---|---|"]
+for k, v in traffic.items():
+    md.append("| `%s` | %s | %.0f | %.0f | %.1f | %.1f |" % (k, v["shape"], v["FETCH_SIZE_KiB_raw"], v["WRITE_SIZE_KiB_raw"],
+                                                          v["traffic_bytes_per_launch"] / 1e6,
+                                                          v["algorithmic_bytes_per_launch"] / 1e6))
+(prof / ("%s_summary.md" % tag)).write_text("\n".join(md) + "\n")
+print("\n".join(md))
