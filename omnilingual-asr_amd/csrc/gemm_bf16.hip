@@ -80,16 +80,17 @@ __device__ __forceinline__ void store_nt16(void* p, u32x4 v) {
     __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
 }
 
-// Stage one 256 x 64 bf16 tile.  Each wave issues 4 global_load_lds of 1 KiB (8 rows each).
-__device__ __forceinline__ void stage_tile(const uint16_t* __restrict__ g, int64_t ld, int64_t row0,
-                                           int64_t k0, char* lds_tile, int wave, int lane) {
+// Stage one 256 x 64 bf16 tile: each wave issues 4 global_load_lds of 1 KiB (8 rows each).  `src`
+// is the wave-uniform address of the wave's first row at this k offset, `lane_off` the lane's
+// constant byte offset inside an 8-row piece (row lane >> 3, swizzled 16-byte chunk), `piece_stride`
+// the bytes between pieces (8 rows): the address of a load is then scalar base + 32-bit lane offset
+// and needs no per-load vector arithmetic.
+__device__ __forceinline__ void stage_tile(const char* __restrict__ src, uint32_t lane_off, int64_t piece_stride,
+                                           char* lds_tile, int wave) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int piece = wave * 4 + i;             // 8 rows per piece
-        const int row = piece * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ (row & 7);   // logical 16-byte chunk this lane must fetch
-        const uint16_t* src = g + (row0 + row) * ld + k0 + chunk * 8;
-        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(lds_tile + piece * 1024), 16, 0, 0);
+        const char* p = src + i * piece_stride;
+        __builtin_amdgcn_global_load_lds((gbl_void*)(p + lane_off), (lds_void*)(lds_tile + (wave * 4 + i) * 1024), 16, 0, 0);
     }
 }
 
@@ -240,12 +241,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(const uint16_t* __restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    const int nt = (int)(K / BK);
+    const int total = my_tiles * nt;
     const int fr = lane & 15, fq = lane >> 4;
     // byte offset of this lane's 16-byte fragment inside a 16-row group, for the two k-halves
     const int off0 = fr * 128 + (((0 + fq) ^ (fr & 7)) << 4);
     const int off1 = fr * 128 + (((4 + fq) ^ (fr & 7)) << 4);
-    const int nt = (int)(K / BK);
-    const int total = my_tiles * nt;
 
     auto tile_origin = [&](int i, int64_t& m0, int64_t& n0) {
         const int l = slot + i * per_xcd;
@@ -258,13 +259,29 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(const uint16_t* __restri
             n0 = (int64_t)((flat_lo + l) % tiles_n) * BN;
         }
     };
-    auto stage_step = [&](int g) {  // global step g = i * nt + t  ->  buffer g & 1
+    // Staging cursor: the next step to copy is K-step st_t of tile st_i; st_a / st_w are the
+    // wave-uniform source addresses of this wave's first A and W row at that k offset.
+    const uint32_t lane_off = (uint32_t)(((lane >> 3) * K + (((lane & 7) ^ (lane >> 3)) << 3)) * 2);
+    const int64_t piece_stride = 8 * K * 2;
+    int st_i = 0, st_t = 0;
+    const char *st_a, *st_w;
+    auto stage_seek = [&](int i) {
         int64_t m0, n0;
-        tile_origin(g / nt, m0, n0);
-        const int64_t k0 = (int64_t)(g % nt) * BK;
-        stage_tile(A, K, m0, k0, smem + (g & 1) * kTileBytes, wave, lane);
-        stage_tile(W, K, n0, k0, smem + (2 + (g & 1)) * kTileBytes, wave, lane);
+        tile_origin(i, m0, n0);
+        st_a = reinterpret_cast<const char*>(A) + (m0 + wave * 32) * K * 2;
+        st_w = reinterpret_cast<const char*>(W) + (n0 + wave * 32) * K * 2;
     };
+    auto stage_step = [&](int g) {  // global step g = st_i * nt + st_t  ->  buffer g & 1
+        stage_tile(st_a, lane_off, piece_stride, smem + (g & 1) * kTileBytes, wave);
+        stage_tile(st_w, lane_off, piece_stride, smem + (2 + (g & 1)) * kTileBytes, wave);
+        st_a += BK * 2;
+        st_w += BK * 2;
+        if (++st_t == nt) {
+            st_t = 0;
+            if (++st_i < my_tiles) stage_seek(st_i);
+        }
+    };
+    stage_seek(0);
 
     stage_step(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
