@@ -1,11 +1,11 @@
 // bf16 MFMA GEMM with fused epilogues for gfx950:  C[m][n] = epi( sum_k A[m][k] * W[n][k] ).
 //
-// Operands.  Both are K-contiguous (activations [m][k], Linear weights [n][k]), so both tiles are
-// staged the same way: 256 rows x 64 k (128-byte rows) per K-step, copied global -> LDS directly by
-// global_load_lds (16 bytes per lane, no VGPR round trip), double buffered.  The LDS image is
-// lane-linear per wave instruction, so the bank-conflict swizzle (16-byte chunk index XOR row&7)
-// is applied to the per-lane *source* address and again on the fragment read (conflict-free
-// ds_read_b128).
+// Operands.  Both are K-contiguous (activations [m][k], Linear weights [n][k]), so both are staged
+// the same way: K runs in slices of 32 (256 rows x 64 bytes per operand), copied global -> LDS
+// directly by global_load_lds (16 bytes per lane, no VGPR round trip) into a ring of four slices.
+// The LDS image is lane-linear per wave instruction (16 rows x 64 bytes), so the bank-conflict
+// swizzle (16-byte chunk index XOR (-(row >> 2) & 3)) is applied to the per-lane *source* address
+// and again on the fragment read (conflict-free ds_read_b128).
 //
 // Tile and waves.  256 x 256 output tile, 8 wavefronts as 2 (m) x 4 (n); a wave owns 128 m x 64 n
 // as 8 x 4 tiles of v_mfma_f32_16x16x32_bf16.  The weight fragment is the MFMA's A operand and the
@@ -13,21 +13,23 @@
 //
 // Schedule (persistent ping-pong).  One work-group per CU walks a list of output tiles.  The 8
 // waves form two groups of 4 (waves 0-3: upper 128 rows, waves 4-7: lower 128 rows); each SIMD
-// hosts one wave of each group.  A phase is one K=32 step of a wave's sub-tile: a LOAD segment
-// (12 ds_read_b128, plus the global_load_lds of the next K-tile) and an MFMA segment (32 MFMAs),
-// separated by raw s_barriers.  Group B runs one barrier behind group A, so on every SIMD one wave
-// is in its MFMA segment while its partner is in its LOAD segment.  The K-steps of consecutive
-// output tiles form ONE continuous pipeline (global step g, LDS buffer g&1): the first K-tile of
-// the next output tile is staged while the current tile's last MFMAs run, and a wave's epilogue
-// overlaps its partner's MFMA segment.
+// hosts one wave of each group.  A phase is one K slice: a LOAD segment (12 ds_read_b128 of slice
+// p, plus this wave's 4 global_load_lds of slice p+2) and an MFMA segment (32 MFMAs), separated by
+// raw s_barriers.  Group B runs one barrier behind group A, so on every SIMD one wave is in its
+// MFMA segment while its partner is in its LOAD segment.  The slices of consecutive output tiles
+// form ONE continuous pipeline (global phase p, ring slot p & 3): the first slices of the next
+// output tile are staged while the current tile's last MFMAs run, and a wave's epilogue overlaps
+// its partner's MFMA segment.  Every LOAD segment carries the same staging work (4 KiB per wave):
+// the copies of all waves of a segment share the CU's one address/texture path, and 8 per wave in
+// one segment made that segment longer than the partner's MFMA segment.
 //
-//   barrier timeline (b_i = i-th barrier, L/M = load/MFMA segment of phase p = 2*step + khalf):
+//   barrier timeline (b_i = i-th barrier, L/M = load/MFMA segment of phase p):
 //     A:  L0 |b0| M0 |b1| L1 |b2| M1 |b3| L2 ...
 //     B:     |b0| L0 |b1| M0 |b2| L1 |b3| M1 ...
-//   Step g+1 is staged into buffer (g+1)&1 during L(2g): every read of step g-1 (same buffer) was
-//   issued before b_(4g-1) and retired by the lgkmcnt wait that precedes the MFMAs, and both
-//   groups' L(2g) come after b_(4g-1).  Each wave waits vmcnt(0) at the end of L(2g+1), i.e. before
-//   b_(4g+2) (A) / b_(4g+3) (B); the first read of step g+1 comes after b_(4g+3).
+//   Slice p+2 goes to ring slot (p+2) & 3, which held slice p-2: its last reads were issued in
+//   B's L(p-2), two barriers before A's L(p).  A wave leaves L(p) with at most its 4 newest copies
+//   outstanding (vmcnt(4); the counter retires in order), so its part of slice p+1 has landed
+//   before b_(2p) (A) / b_(2p+1) (B); slice p+1 is first read after b_(2p+1).
 //
 // Epilogue.  Each 16-row slice of a wave's sub-tile is bounced through a wave-private LDS slab and
 // leaves as 16-byte-per-lane stores covering 8 rows x 128 contiguous bytes.  Outputs are written
@@ -38,8 +40,9 @@
 
 namespace oasr {
 
-constexpr int BM = 256, BN = 256, BK = 64;
-constexpr int kTileBytes = BM * BK * 2;   // 32 KiB per operand per buffer
+constexpr int BM = 256, BN = 256, BK = 32;
+constexpr int kSliceBytes = BM * BK * 2;   // 16 KiB per operand per ring slot
+constexpr int kRing = 4;
 constexpr int kEpiPitch = 144;            // bytes per slab row: 16-byte aligned, <= 2-way write conflicts
 constexpr int kEpiSlab = 16 * kEpiPitch;  // bytes per wave
 constexpr int kMaxCUs = 256;
@@ -80,31 +83,45 @@ __device__ __forceinline__ void store_nt16(void* p, u32x4 v) {
     __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
 }
 
-// Stage one 256 x 64 bf16 tile: each wave issues 4 global_load_lds of 1 KiB (8 rows each).  `src`
-// is the wave-uniform address of the wave's first row at this k offset, `lane_off` the lane's
-// constant byte offset inside an 8-row piece (row lane >> 3, swizzled 16-byte chunk), `piece_stride`
-// the bytes between pieces (8 rows): the address of a load is then scalar base + 32-bit lane offset
-// and needs no per-load vector arithmetic.
-__device__ __forceinline__ void stage_tile(const char* __restrict__ src, uint32_t lane_off, int64_t piece_stride,
-                                           char* lds_tile, int wave) {
+// Stage this wave's part of one K slice of one operand (256 rows x 64 bytes): 2 global_load_lds of
+// 1 KiB (16 rows each).  `src` is the wave-uniform address of the wave's first row at this k
+// offset, `lane_off` the lane's constant byte offset inside a 16-row piece (row lane >> 2,
+// swizzled 16-byte chunk), `piece_stride` the bytes between pieces: the address of a load is then
+// scalar base + 32-bit lane offset and needs no per-load vector arithmetic.
+__device__ __forceinline__ void stage_slice(const char* __restrict__ src, uint32_t lane_off, int64_t piece_stride,
+                                            char* lds_slice, int wave) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2; ++i) {
         const char* p = src + i * piece_stride;
-        __builtin_amdgcn_global_load_lds((gbl_void*)(p + lane_off), (lds_void*)(lds_tile + (wave * 4 + i) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(p + lane_off), (lds_void*)(lds_slice + (wave * 2 + i) * 1024), 16, 0, 0);
+    }
+}
+
+// Bias values of one output tile in the layout its epilogue consumes: per fragment column for the
+// bf16 epilogues (bv[j] = bias[nbase + 16 j + 4 fq ..]), per read-back chunk for the float32 ones
+// (bv[h] = bias[nbase + 32 h + 4 (lane & 7) ..]).  Loaded at the start of a tile so that the
+// epilogue does not begin with a memory round trip.
+template <int EPI>
+__device__ __forceinline__ void load_bias(float4 (&bv)[4], const float* __restrict__ bias, int64_t nbase, int lane) {
+    if (EPI == OASR_EPI_GLU_BF16) return;
+    if (EPI == OASR_EPI_BIAS_BF16 || EPI == OASR_EPI_BIAS_SWISH_BF16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            bv[j] = bias ? *reinterpret_cast<const float4*>(bias + nbase + j * 16 + (lane >> 4) * 4) : make_float4(0, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            bv[h] = bias ? *reinterpret_cast<const float4*>(bias + nbase + h * 32 + (lane & 7) * 4) : make_float4(0, 0, 0, 0);
     }
 }
 
 // acc[i][j]: lane (fr = lane & 15, fq = lane >> 4) holds C[mbase + 16 i + fr][nbase + 16 j + 4 fq + 0..3].
 template <int EPI>
-__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[8][4], const float* __restrict__ bias,
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[8][4], const float4 (&bv)[4],
                                               const float* resid, void* C, int64_t N, float alpha,
                                               int64_t mbase, int64_t nbase, int lane, char* slab) {
     const int fr = lane & 15, fq = lane >> 4;
     if (EPI == OASR_EPI_BIAS_BF16 || EPI == OASR_EPI_BIAS_SWISH_BF16) {
-        float4 bv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            bv[j] = bias ? *reinterpret_cast<const float4*>(bias + nbase + j * 16 + fq * 4) : make_float4(0, 0, 0, 0);
         const int rrow = lane >> 3, rchunk = lane & 7;   // read-back role: rows rrow, rrow + 8; 16-byte chunk
         uint16_t* cbase = reinterpret_cast<uint16_t*>(C) + (mbase + rrow) * N + nbase + rchunk * 8;
 #pragma unroll
@@ -146,10 +163,6 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[8][4], const float* _
         }
     } else {  // float32 outputs: two 32-column halves per 16-row slice
         const int rrow = lane >> 3, rchunk = lane & 7;
-        float4 bv[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            bv[h] = bias ? *reinterpret_cast<const float4*>(bias + nbase + h * 32 + rchunk * 4) : make_float4(0, 0, 0, 0);
         // element index of (slice i, half h, row-pair r2) for this lane's read-back role
         auto index_of = [&](int i, int h, int r2) {
             return (mbase + i * 16 + rrow + 8 * r2) * N + nbase + h * 32 + rchunk * 4;
@@ -210,7 +223,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(const uint16_t* __restri
                                                         const float* __restrict__ bias,
                                                         const float* resid, void* C, int64_t N,
                                                         int64_t K, float alpha, int n_tiles) {
-    __shared__ __attribute__((aligned(1024))) char smem[4 * kTileBytes + 8 * kEpiSlab];  // A0 A1 B0 B1 | slabs
+    __shared__ __attribute__((aligned(1024))) char smem[2 * kRing * kSliceBytes + 8 * kEpiSlab];  // A ring | W ring | slabs
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -241,12 +254,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(const uint16_t* __restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nt = (int)(K / BK);
-    const int total = my_tiles * nt;
+    const int nph = (int)(K / BK);          // phases (K slices) per output tile
+    const int total = my_tiles * nph;
     const int fr = lane & 15, fq = lane >> 4;
-    // byte offset of this lane's 16-byte fragment inside a 16-row group, for the two k-halves
-    const int off0 = fr * 128 + (((0 + fq) ^ (fr & 7)) << 4);
-    const int off1 = fr * 128 + (((4 + fq) ^ (fr & 7)) << 4);
+    // byte offset of this lane's 16-byte fragment inside a 16-row group of a slice
+    const int off = fr * 64 + ((fq ^ ((4 - (fr >> 2)) & 3)) << 4);
 
     auto tile_origin = [&](int i, int64_t& m0, int64_t& n0) {
         const int l = slot + i * per_xcd;
@@ -259,10 +271,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(const uint16_t* __restri
             n0 = (int64_t)((flat_lo + l) % tiles_n) * BN;
         }
     };
-    // Staging cursor: the next step to copy is K-step st_t of tile st_i; st_a / st_w are the
+    // Staging cursor: the next slice to copy is slice st_t of tile st_i; st_a / st_w are the
     // wave-uniform source addresses of this wave's first A and W row at that k offset.
-    const uint32_t lane_off = (uint32_t)(((lane >> 3) * K + (((lane & 7) ^ (lane >> 3)) << 3)) * 2);
-    const int64_t piece_stride = 8 * K * 2;
+    const uint32_t lane_off =
+        (uint32_t)(((lane >> 2) * K + (((lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3)) << 3)) * 2);
+    const int64_t piece_stride = 16 * K * 2;
     int st_i = 0, st_t = 0;
     const char *st_a, *st_w;
     auto stage_seek = [&](int i) {
@@ -271,59 +284,66 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(const uint16_t* __restri
         st_a = reinterpret_cast<const char*>(A) + (m0 + wave * 32) * K * 2;
         st_w = reinterpret_cast<const char*>(W) + (n0 + wave * 32) * K * 2;
     };
-    auto stage_step = [&](int g) {  // global step g = st_i * nt + st_t  ->  buffer g & 1
-        stage_tile(st_a, lane_off, piece_stride, smem + (g & 1) * kTileBytes, wave);
-        stage_tile(st_w, lane_off, piece_stride, smem + (2 + (g & 1)) * kTileBytes, wave);
+    auto stage_next = [&](int p) {  // global phase p = st_i * nph + st_t  ->  ring slot p & 3
+        stage_slice(st_a, lane_off, piece_stride, smem + (p & 3) * kSliceBytes, wave);
+        stage_slice(st_w, lane_off, piece_stride, smem + (kRing + (p & 3)) * kSliceBytes, wave);
         st_a += BK * 2;
         st_w += BK * 2;
-        if (++st_t == nt) {
+        if (++st_t == nph) {
             st_t = 0;
             if (++st_i < my_tiles) stage_seek(st_i);
         }
     };
     stage_seek(0);
 
-    stage_step(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stage_next(0);
+    if (total > 1) {
+        stage_next(1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     OASR_RAW_BARRIER();
     if (wm == 1) OASR_RAW_BARRIER();  // group B runs one barrier behind
 
     bf16x8 xf[8], wf[4];
-    int g = 0;
+    int p = 0;
+    float4 bv[4];
     for (int i = 0; i < my_tiles; ++i) {
-        for (int t = 0; t < nt; ++t, ++g) {
-            const int cur = g & 1;
-            const char* sa = smem + cur * kTileBytes + (wm * 128) * 128;
-            const char* sb = smem + (2 + cur) * kTileBytes + (wn * 64) * 128;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int off = kk ? off1 : off0;
-                // ---- LOAD segment
-#pragma unroll
-                for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 128 + off);
-#pragma unroll
-                for (int ii = 0; ii < 8; ++ii) xf[ii] = *reinterpret_cast<const bf16x8*>(sa + ii * 16 * 128 + off);
-                if (kk == 0) {
-                    if (g + 1 < total) stage_step(g + 1);
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                OASR_RAW_BARRIER();
-                // ---- MFMA segment
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int ii = 0; ii < 8; ++ii)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[ii], acc[ii][j], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
-                OASR_RAW_BARRIER();
-            }
-        }
         int64_t m0, n0;
         tile_origin(i, m0, n0);
-        gemm_epilogue<EPI>(acc, bias, resid, C, N, alpha, m0 + wm * 128, n0 + wn * 64, lane,
-                           smem + 4 * kTileBytes + wave * kEpiSlab);
+        load_bias<EPI>(bv, bias, n0 + wn * 64, lane);
+        for (int t = 0; t < nph; ++t, ++p) {
+            const char* sa = smem + (p & 3) * kSliceBytes + (wm * 128) * 64 + off;
+            const char* sb = smem + (kRing + (p & 3)) * kSliceBytes + (wn * 64) * 64 + off;
+            // ---- LOAD segment
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 64);
+#pragma unroll
+            for (int ii = 0; ii < 8; ++ii) xf[ii] = *reinterpret_cast<const bf16x8*>(sa + ii * 16 * 64);
+            if (p + 2 < total) {
+                stage_next(p + 2);
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            OASR_RAW_BARRIER();
+            // ---- MFMA segment
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ii = 0; ii < 8; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[ii], acc[ii][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            // Group B holds the barrier that ends a tile's last MFMA segment until its epilogue is
+            // done, so that the two groups' epilogues overlap instead of running one after the other
+            // (group A's epilogue + first LOAD segment already sit between the same two barriers).
+            if (!(wm == 1 && t == nph - 1)) OASR_RAW_BARRIER();
+        }
+        gemm_epilogue<EPI>(acc, bv, resid, C, N, alpha, m0 + wm * 128, n0 + wn * 64, lane,
+                           smem + 2 * kRing * kSliceBytes + wave * kEpiSlab);
+        if (wm == 1) OASR_RAW_BARRIER();
 #pragma unroll
         for (int ii = 0; ii < 8; ++ii)
 #pragma unroll
@@ -341,7 +361,7 @@ extern "C" int oasr_gemm_bf16(const uint16_t* a, const uint16_t* w, const float*
                               float alpha, int32_t epilogue, void* stream) {
     OASR_REQUIRE(a && w && c, "gemm: null pointer");
     OASR_REQUIRE(m > 0 && n > 0 && k > 0 && m % BM == 0 && n % BN == 0 && k % BK == 0,
-                 "gemm: m=%lld n=%lld must be multiples of 256 and k=%lld of 64", (long long)m,
+                 "gemm: m=%lld n=%lld must be multiples of 256 and k=%lld of 32", (long long)m,
                  (long long)n, (long long)k);
     OASR_REQUIRE((m / BM) * (n / BN) < ((int64_t)1 << 30), "gemm: too many tiles");
     OASR_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)c & 15) == 0 &&

@@ -1,11 +1,9 @@
 #!/usr/bin/env python3
-"""Read the per-tile cycle stamps of the diagnostic GEMM build (tuning aid)."""
+"""Read the per-segment cycle sums of the diagnostic GEMM build (tuning aid)."""
 import ctypes as C, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
-sys.path.insert(0, str(ROOT / "omnilingual-asr_amd"))
 import numpy as np, torch
-from omnilingual_asr import _hip
 lib = C.CDLL(str(ROOT / "omnilingual-asr_amd/lib/abl_stamp.so"))
 m, n, k, epi = 48128, 4096, 1024, 1
 if len(sys.argv) > 1: m, n, k, epi = [int(v) for v in sys.argv[1:5]]
@@ -23,11 +21,9 @@ torch.cuda.synchronize()
 buf = np.zeros(8192, dtype=np.uint64)
 lib.oasr_debug_read.argtypes = [vp, C.c_int64]
 assert lib.oasr_debug_read(buf.ctypes.data, buf.nbytes) == 0
+print("per phase averages (ticks): ds_read+drain  dma-issue  vmwait  bar1  mfma  bar2")
 for wg in range(2):
-    for wv in range(2):
-        b = buf[(wg * 2 + wv) * 256:(wg * 2 + wv + 1) * 256].astype(np.int64).reshape(-1, 8)
-        n = int((b[:, 0] != 0).sum())
-        main = (b[:n, 1] - b[:n, 0])
-        epi = (b[:n, 3] - b[:n, 1])
-        period = np.diff(b[:n, 0])
-        print(f"wg{wg} group{'AB'[wv]}: tiles {n}  main {np.median(main):8.0f}  epilogue {np.median(epi):7.0f}  period {np.median(period) if n > 1 else 0:8.0f}  total {b[n-1,3]-b[0,0]:9d} ticks")
+    for wv in (0, 4):
+        b = buf[(wg * 8 + wv) * 16:(wg * 8 + wv + 1) * 16].astype(np.float64)
+        steps = b[10]
+        print(f"wg{wg} wave{wv}: " + " ".join(f"{b[q]/steps:7.0f}" for q in range(6)) + f"   sum {sum(b[:6])/steps:7.0f}")
