@@ -132,7 +132,8 @@ typedef struct oasr_layer_weights {
     const uint16_t* ffn1_w1; const float* ffn1_b1;   /* [ffn][d] */
     const uint16_t* ffn1_w2; const float* ffn1_b2;   /* [d][ffn] */
     const float *attn_ln_w, *attn_ln_b;
-    const uint16_t* wqkv; const float* bqkv;         /* [3d][d]: q rows, then k rows, then v rows */
+    const uint16_t* wqkv; const float* bqkv;         /* [3d][d]: q rows, then k rows, then v rows;
+                                                        q rows and q bias pre-multiplied by log2(e)/sqrt(head) */
     const uint16_t* wo; const float* bo;             /* [d][d] */
     const uint16_t* dist_emb;                        /* [96][64] bf16, rows >= left+right+1 zero */
     const float *conv_ln_w, *conv_ln_b;
@@ -207,7 +208,9 @@ int oasr_gemm_bf16(const uint16_t* a, const uint16_t* w, const float* bias, cons
                    void* stream);
 
 /* Multi-head self-attention with clamped relative-key bias and key-length masking.
- * qkv bf16 [rows][3*d] (q | k | v), ctx bf16 [rows][d]; head size 64. */
+ * qkv bf16 [rows][3*d] (q | k | v), ctx bf16 [rows][d]; head size 64.  The kernel works in log2
+ * units: q must arrive multiplied by log2(e)/sqrt(64) (the encoder folds that factor into the q
+ * rows of wqkv/bqkv), k and v unscaled. */
 int oasr_attention_relkey(const uint16_t* qkv, const uint16_t* dist_emb, const int32_t* lengths,
                           uint16_t* ctx, int32_t batch, int64_t t_pad, int32_t n_heads,
                           int32_t left_max, int32_t right_max, void* stream);

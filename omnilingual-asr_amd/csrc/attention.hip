@@ -1,13 +1,21 @@
 // Fused multi-head self-attention for gfx950 with clamped relative-key bias and key-length mask:
 //   scores[i][j] = (q_i . k_j + q_i . E[clip(j - i, -L, R) + L]) / sqrt(64);  softmax over j < len;
 //   ctx_i = sum_j p[i][j] v_j.
+// The caller hands in q already multiplied by log2(e) / sqrt(64) (folded into the q rows of the
+// fused projection), so the MFMA results are scores in log2 units and no per-element scaling is left.
 // Flash-style: the T x T scores never leave the CU.  A 256-thread work-group owns 128 query rows
 // of one (utterance, head); each wavefront owns 32 of them and walks the keys in tiles of 64.
 //
 // MFMA orientation (v_mfma_f32_32x32x16_bf16): S^T = K . Q^T, so a lane holds one query column and
-// 16 keys of it in registers — row max / row sum are in-register plus one exchange with lane^32,
-// and the rescale factor is a per-lane scalar.  The S^T accumulator, converted to bf16, is directly
-// the B operand of O^T = V^T . P^T (summing over its row index), so P never touches LDS.
+// 16 keys of it in registers — the row max is in-register plus one exchange with lane^32, and the
+// rescale factor is a per-lane scalar.  The S^T accumulator, converted to bf16, is directly the B
+// operand of O^T = V^T . P^T (summing over its row index), so P never touches LDS; the row sums come
+// from one more MFMA per k-step with an all-ones A operand (every row of its result is the column
+// sum of P^T), which moves 32 additions per lane and tile from the vector ALU to the matrix pipe.
+// Softmax bookkeeping is relative to a lazily raised running max m: the S^T accumulators start from
+// (bias - m) instead of zero in tiles where the relative-key term is one value per query, so there
+// p = exp2(accumulator) with no arithmetic in between; m moves (and O, the sums and the tile's
+// scores are rescaled) only when some score exceeds it by more than a threshold.
 // The relative-key term needs only the L+R+1 distinct values q_i . E[c]: they are computed once per
 // wave by MFMA into LDS; key tiles entirely left (right) of the clamp window use one register value.
 #include <type_traits>
@@ -120,17 +128,22 @@ __global__ __launch_bounds__(256, 2) void attention_relkey_kernel(
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    const float cs = 1.4426950408889634f * 0.125f;  // log2(e) / sqrt(64)
-    const float bias_left = wave_active ? qe[0 * 32 + r] * cs : 0.f;
-    const float bias_right = wave_active ? qe[(n_dist - 1) * 32 + r] * cs : 0.f;
+    const float bias_left = wave_active ? qe[0 * 32 + r] : 0.f;
+    const float bias_right = wave_active ? qe[(n_dist - 1) * 32 + r] : 0.f;
 
-    f32x16 o0, o1;
+    f32x16 o0, o1, lacc, offv;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         o0[e] = 0.f;
         o1[e] = 0.f;
+        lacc[e] = 0.f;
+        offv[e] = 0.f;
     }
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = 0.f;       // running max (log2 units); set from the first tile's true max
+    bool first_tile = true;  // wave-uniform
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;   // bf16 1.0
 
     // ---- staging roles ------------------------------------------------------------------------------------
     // K: thread copies 16-byte chunks (key = tid >> 3 (+32), chunk = tid & 7)
@@ -187,11 +200,13 @@ __global__ __launch_bounds__(256, 2) void attention_relkey_kernel(
     __syncthreads();
 
     // One key tile.  FAR: every (query, key) distance of this wave's rows lies outside the clamp
-    // window on one side and no key is masked, so the relative-key term is one value per lane.  The
-    // two cases are separate loops below (not a flag inside one loop) so that the far path does not
-    // carry the per-element table gather and masking of the general path.
-    auto process_tile = [&](auto far_c, int kt, float bias) {
-        constexpr bool FAR = decltype(far_c)::value;
+    // window on one side and no key is masked, so the relative-key term is one value per lane and
+    // the accumulators start from offv = (that value - m_run).  NEAR: per-element table gather.
+    // NEAR_MASKED: the last tile when it has keys >= len.  The cases are separate loops below (not
+    // flags inside one loop) so that the far path carries none of the gather and masking code.
+    constexpr int FAR = 0, NEAR = 1, NEAR_MASKED = 2;
+    auto process_tile = [&](auto kind_c, int kt) {
+        constexpr int KIND = decltype(kind_c)::value;
         const int buf = kt & 1;
         // stage tile kt+1 (already in registers) into the other buffer, then request tile kt+2
         if (kt + 1 < n_tiles) {
@@ -202,12 +217,17 @@ __global__ __launch_bounds__(256, 2) void attention_relkey_kernel(
             const int k0 = kt * kKTile;
             const char* kbuf = sm.k[buf];
             const char* vbuf = sm.vt[buf];
-            // ---- S^T = K . Q^T for the two 32-key halves ------------------------------------------------
+            // ---- S^T = K . Q^T for the two 32-key halves (relative to m_run in the FAR case) ---------------
             f32x16 s0, s1;
+            if (KIND == FAR) {
+                s0 = offv;
+                s1 = offv;
+            } else {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                s0[e] = 0.f;
-                s1[e] = 0.f;
+                for (int e = 0; e < 16; ++e) {
+                    s0[e] = 0.f;
+                    s1[e] = 0.f;
+                }
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -216,58 +236,53 @@ __global__ __launch_bounds__(256, 2) void attention_relkey_kernel(
                 s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], s0, 0, 0, 0);
                 s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb, qf[s], s1, 0, 0, 0);
             }
-            // ---- log2-domain scores t = s * cs + bias; softmax with a lazily raised running max ------------
-            float psum = 0.f;
-            if (FAR) {
-                float tmax = max32(s0, s1) * cs + bias;
-                tmax = vmax(tmax, __shfl_xor(tmax, 32, 64));
-                // both lanes of a query (r, r + 32) see the same tmax and m_run: same decision
-                const float m_new = tmax > m_run + kRescaleThreshold ? tmax : m_run;
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // 1 when unchanged
-                m_run = m_new;
-                l_run *= alpha;
+            if (KIND != FAR) {
+                // c = clamp(key - q, -L, R) + L = med3(dbase + krow, 0, L + R)
+                const int dbase = k0 - (qw0 + r) + left_max + 4 * hh;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    o0[e] *= alpha;
-                    o1[e] *= alpha;
-                }
-                const float off = bias - m_run;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    s0[e] = __builtin_amdgcn_exp2f(fmaf(s0[e], cs, off));
-                    s1[e] = __builtin_amdgcn_exp2f(fmaf(s1[e], cs, off));
-                    psum += s0[e] + s1[e];
-                }
-            } else {
-                const int q = qw0 + r;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                    const int c0 = min(max(key - q, -left_max), right_max) + left_max;
-                    const int c1 = min(max(key + 32 - q, -left_max), right_max) + left_max;
-                    s0[e] = key < len ? (s0[e] + qe[c0 * 32 + r]) * cs : -INFINITY;
-                    s1[e] = key + 32 < len ? (s1[e] + qe[c1 * 32 + r]) * cs : -INFINITY;
-                }
-                float tmax = max32(s0, s1);
-                tmax = vmax(tmax, __shfl_xor(tmax, 32, 64));
-                const float m_new = tmax > m_run + kRescaleThreshold ? tmax : m_run;
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-                m_run = m_new;
-                l_run *= alpha;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    o0[e] *= alpha;
-                    o1[e] *= alpha;
-                }
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    s0[e] = __builtin_amdgcn_exp2f(s0[e] - m_run);
-                    s1[e] = __builtin_amdgcn_exp2f(s1[e] - m_run);
-                    psum += s0[e] + s1[e];
+                    const int krow = (e & 3) + 8 * (e >> 2);
+                    const int c0 = min(max(dbase + krow, 0), n_dist - 1);
+                    const int c1 = min(max(dbase + krow + 32, 0), n_dist - 1);
+                    const float t0 = s0[e] + (qe[c0 * 32 + r] - m_run);
+                    const float t1 = s1[e] + (qe[c1 * 32 + r] - m_run);
+                    if (KIND == NEAR_MASKED) {
+                        const int key = k0 + krow + 4 * hh;
+                        s0[e] = key < len ? t0 : -INFINITY;
+                        s1[e] = key + 32 < len ? t1 : -INFINITY;
+                    } else {
+                        s0[e] = t0;
+                        s1[e] = t1;
+                    }
                 }
             }
-            l_run += psum;
-            // ---- O^T += V^T . P^T ---------------------------------------------------------------------------
+            // ---- raise the running max if needed (always on the first tile) ---------------------------------
+            float tmax = max32(s0, s1);
+            tmax = vmax(tmax, __shfl_xor(tmax, 32, 64));
+            // both lanes of a query (r, r + 32) see the same tmax and m_run: same decision
+            const bool raise = first_tile || tmax > kRescaleThreshold;
+            if (__builtin_amdgcn_ballot_w64(raise) != 0) {
+                const float delta = raise ? tmax : 0.f;
+                const float alpha = first_tile ? 1.f : __builtin_amdgcn_exp2f(-delta);   // O and sums are 0 at first
+                m_run += delta;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    o0[e] *= alpha;
+                    o1[e] *= alpha;
+                    lacc[e] *= alpha;
+                    s0[e] -= delta;
+                    s1[e] -= delta;
+                    offv[e] -= delta;
+                }
+                first_tile = false;
+            }
+            // ---- p = exp2(score - m_run) -----------------------------------------------------------------------
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                s0[e] = __builtin_amdgcn_exp2f(s0[e]);
+                s1[e] = __builtin_amdgcn_exp2f(s1[e]);
+            }
+            // ---- O^T += V^T . P^T and row sums += 1 . P^T ---------------------------------------------------
             // k-step (u, s2): P fragment = registers 8 s2 .. 8 s2 + 7 of S_u; its element j is key
             // 32 u + 16 s2 + 8 (j >> 2) + 4 hh + (j & 3), so V^T is read as two 8-byte pieces.
 #pragma unroll
@@ -294,10 +309,16 @@ __global__ __launch_bounds__(256, 2) void attention_relkey_kernel(
                         else
                             o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o1, 0, 0, 0);
                     }
+                    lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);
                 }
             }
         }
         __syncthreads();  // tile kt+1 is staged; everyone is done reading buffer kt & 1
+    };
+    // start value of the S^T accumulators in FAR tiles
+    auto set_far_bias = [&](float bias) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) offv[e] = bias - m_run;
     };
 
     // Tile ranges of this wave (wave-uniform; every wave still runs n_tiles tiles = n_tiles barriers):
@@ -311,15 +332,16 @@ __global__ __launch_bounds__(256, 2) void attention_relkey_kernel(
     n_left = min(n_left, n_full);
     first_r = min(max(first_r, n_left), n_full);
     int kt = 0;
-    for (; kt < n_left; ++kt) process_tile(std::true_type{}, kt, bias_left);
-    for (; kt < first_r; ++kt) process_tile(std::false_type{}, kt, 0.f);
-    for (; kt < n_full; ++kt) process_tile(std::true_type{}, kt, bias_right);
-    for (; kt < n_tiles; ++kt) process_tile(std::false_type{}, kt, 0.f);
+    set_far_bias(bias_left);
+    for (; kt < n_left; ++kt) process_tile(std::integral_constant<int, FAR>{}, kt);
+    for (; kt < first_r; ++kt) process_tile(std::integral_constant<int, NEAR>{}, kt);
+    set_far_bias(bias_right);
+    for (; kt < n_full; ++kt) process_tile(std::integral_constant<int, FAR>{}, kt);
+    for (; kt < n_tiles; ++kt) process_tile(std::integral_constant<int, NEAR_MASKED>{}, kt);
 
     if (!wave_active) return;
     // ---- normalise and store: lane holds ctx[q][32 db + 8 g + 4 hh + {0..3}] ---------------------------------
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
+    const float inv = 1.0f / lacc[0];   // every row of the ones-product is the full row sum
     const int q = qw0 + r;
     if (q < t_pad) {
         uint16_t* op = ctx + ((int64_t)b * t_pad + q) * d_model + head * kHead + 4 * hh;

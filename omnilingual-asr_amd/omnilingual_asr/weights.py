@@ -122,6 +122,10 @@ def glu_interleave(pw1: torch.Tensor) -> torch.Tensor:
     return torch.cat([val, gate], dim=1).reshape(2 * d, -1).contiguous()
 
 
+# log2(e): `oasr_attention_relkey` works in log2 units and expects q * log2(e) / sqrt(head_dim)
+ATTENTION_Q_SCALE = 1.4426950408889634
+
+
 def pack_for_device(weights: dict, g: Geometry, device) -> dict:
     """Device tensors in the layout of `oasr_layer_weights` / `oasr_top_weights` (include/oasr.h)."""
     bf = lambda t: t.to(device=device, dtype=torch.bfloat16).contiguous()
@@ -131,12 +135,14 @@ def pack_for_device(weights: dict, g: Geometry, device) -> dict:
     top = {"fp_ln_w": f32(weights["fp_ln_w"]), "fp_ln_b": f32(weights["fp_ln_b"]),
            "fp_w": bf(fp_w), "fp_b": f32(weights["fp_b"])}
     layers = []
+    q_scale = ATTENTION_Q_SCALE / math.sqrt(g.head_dim)
     for L in weights["layers"]:
         dist = torch.zeros((96, g.head_dim), dtype=torch.float32)
         dist[: g.n_dist] = L["dist_emb"]
         P = {
-            "wqkv": bf(torch.cat([L["wq"], L["wk"], L["wv"]], dim=0)),
-            "bqkv": f32(torch.cat([L["bq"], L["bk"], L["bv"]], dim=0)),
+            # the attention kernel takes q in log2 units: log2(e) / sqrt(head) folded into the q rows
+            "wqkv": bf(torch.cat([L["wq"] * q_scale, L["wk"], L["wv"]], dim=0)),
+            "bqkv": f32(torch.cat([L["bq"] * q_scale, L["bk"], L["bv"]], dim=0)),
             "wo": bf(L["wo"]), "bo": f32(L["bo"]),
             "dist_emb": bf(dist),
             "pw1": bf(glu_interleave(L["pw1"])),

@@ -219,13 +219,25 @@ def _attention_ref(qkv, dist_emb, lengths, n_heads, left, right):
     return (p @ v).transpose(1, 2).reshape(b, t, d)
 
 
+def _prescale_q(qkv, d):
+    """The kernel takes q * log2(e) / sqrt(64), rounded to bf16: returns (device qkv, the float qkv whose
+    q is exactly that rounded value scaled back, for the reference)."""
+    cs = 1.4426950408889634 / 8.0
+    dev = qkv.clone().float()
+    dev[..., :d] = dev[..., :d] * cs
+    dev = _bf(dev)
+    ref = dev.float().clone()
+    ref[..., :d] = ref[..., :d] / cs
+    return dev, ref
+
+
 @pytest.mark.parametrize("batch,t_pad,lens,heads", [(2, 256, [256, 131], 2), (1, 1504, [1499], 1),
                                                     (3, 96, [96, 1, 70], 4)])
 def test_attention_relkey(batch, t_pad, lens, heads):
     H = _lib()
     g = torch.Generator().manual_seed(t_pad + heads)
     d = heads * 64
-    qkv = _bf(torch.randn((batch, t_pad, 3 * d), generator=g))
+    qkv, qkv_ref = _prescale_q(torch.randn((batch, t_pad, 3 * d), generator=g), d)
     emb = torch.zeros((96, 64))
     emb[:73] = torch.randn((73, 64), generator=g)
     emb = _bf(emb)
@@ -238,7 +250,7 @@ def test_attention_relkey(batch, t_pad, lens, heads):
     H.check(H.lib().oasr_attention_relkey(qkv_d.data_ptr(), emb_d.data_ptr(), len_d.data_ptr(),
                                           ctx.data_ptr(), batch, t_pad, heads, 64, 8, _stream()))
     torch.cuda.synchronize()
-    ref = _attention_ref(qkv.float(), emb.float()[:73], lengths.long(), heads, 64, 8)
+    ref = _attention_ref(qkv_ref, emb.float()[:73], lengths.long(), heads, 64, 8)
     got = ctx[: batch * t_pad].float().cpu().reshape(batch, t_pad, d).double()
     for i, n in enumerate(lens):
         # P is rounded to bf16 before P.V and the output is bf16: 2^-8 relative on |ctx| <~ 3
@@ -255,7 +267,7 @@ def test_attention_online_softmax_rescale_is_exercised():
     qkv = torch.randn((batch, t_pad, 3 * d), generator=g) * 0.5
     qkv[0, :, :d] = qkv[0, :, :d].abs()                 # positive queries
     qkv[0, 200, d:2 * d] = 6.0                          # one key with a large positive dot product
-    qkv = _bf(qkv)
+    qkv, qkv_ref = _prescale_q(qkv, d)
     emb = _bf(torch.zeros((96, 64)))
     lengths = torch.tensor([t_pad], dtype=torch.int32)
     ctx = torch.zeros((256, d), dtype=torch.bfloat16, device="cuda")
@@ -263,7 +275,7 @@ def test_attention_online_softmax_rescale_is_exercised():
     H.check(H.lib().oasr_attention_relkey(qkv_d.data_ptr(), emb_d.data_ptr(), len_d.data_ptr(), ctx.data_ptr(),
                                           batch, t_pad, heads, 64, 8, _stream()))
     torch.cuda.synchronize()
-    ref = _attention_ref(qkv.float(), emb.float()[:73], lengths.long(), heads, 64, 8)
+    ref = _attention_ref(qkv_ref, emb.float()[:73], lengths.long(), heads, 64, 8)
     torch.testing.assert_close(ctx.float().cpu().reshape(1, t_pad, d).double(), ref, atol=3e-2, rtol=3e-2)
 
 

@@ -12,7 +12,9 @@ d = heads * 64
 dev = torch.device("cuda")
 g = torch.Generator().manual_seed(1)
 rows = (batch * t_pad + 255) // 256 * 256
-qkv = torch.randn((rows, 3 * d), generator=g).to(torch.bfloat16).to(dev)
+qkv = torch.randn((rows, 3 * d), generator=g)
+qkv[:, :d] *= 1.4426950408889634 / 8.0   # the kernel takes q in log2 units
+qkv = qkv.to(torch.bfloat16).to(dev)
 emb = torch.zeros((96, 64)); emb[:73] = torch.randn((73, 64), generator=g)
 emb = emb.to(torch.bfloat16).to(dev)
 lens = torch.full((batch,), T, dtype=torch.int32, device=dev)
