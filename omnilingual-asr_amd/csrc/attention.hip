@@ -167,11 +167,16 @@ __global__ __launch_bounds__(256, 2) void attention_relkey_kernel(
         const int key = k0 + 2 * kp;
         vreg0 = *reinterpret_cast<const uint4*>(vb + min(key, last_row) * ld);
         vreg1 = *reinterpret_cast<const uint4*>(vb + min(key + 1, last_row) * ld);
-        // masked keys must not inject non-finite values
-        if (key >= len) vreg0 = make_uint4(0, 0, 0, 0);
-        if (key + 1 >= len) vreg1 = make_uint4(0, 0, 0, 0);
     };
-    auto store_tile = [&](int buf) {
+    // `kt` = the tile held in the prefetch registers.  Masked keys (only in the last tile) must not
+    // inject non-finite values into P.V: their V rows are zeroed here, after the loads have landed
+    // (doing it where the loads are issued would wait for them on the spot).
+    auto store_tile = [&](int buf, int kt) {
+        if ((kt + 1) * kKTile > len) {
+            const int key = kt * kKTile + 2 * kp;
+            if (key >= len) vreg0 = make_uint4(0, 0, 0, 0);
+            if (key + 1 >= len) vreg1 = make_uint4(0, 0, 0, 0);
+        }
         *reinterpret_cast<uint4*>(sm.k[buf] + k_lds0) = kreg0;
         *reinterpret_cast<uint4*>(sm.k[buf] + k_lds1) = kreg1;
         char* vt = sm.vt[buf] + vt_lds;
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void attention_relkey_kernel(
     constexpr int vt_sw0 = 0, vt_sw1 = 8;   // ((row >> 5) & 1) << 3 for rows r and 32 + r
 
     load_tile(0);
-    store_tile(0);
+    store_tile(0, 0);
     if (n_tiles > 1) load_tile(1);
     __syncthreads();
 
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void attention_relkey_kernel(
         const int buf = kt & 1;
         // stage tile kt+1 (already in registers) into the other buffer, then request tile kt+2
         if (kt + 1 < n_tiles) {
-            store_tile(buf ^ 1);
+            store_tile(buf ^ 1, kt + 1);
             if (kt + 2 < n_tiles) load_tile(kt + 2);
         }
         if (wave_active) {
