@@ -29,7 +29,6 @@ constexpr int kKTile = 64;     // keys per iteration
 constexpr int kHead = 64;      // head size
 constexpr int kDistRows = 96;  // rows of the (zero padded) distance-embedding table in global memory
 constexpr int kQeRows = 80;    // rows of q.E kept in LDS (>= left_max + right_max + 1)
-constexpr int kVtPitch = 136;  // bytes per V^T row in LDS: 64 keys * 2 B + 8 B pad (conflict-free b64 reads)
 constexpr float kRescaleThreshold = 6.0f;  // log2 units: the running max is raised only past this
 
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
@@ -58,16 +57,18 @@ __device__ __forceinline__ float max32(const f32x16& a, const f32x16& b) {
 // LDS images, double buffered (one barrier per key tile):
 //   k : [key][64 d] bf16, 128-byte rows; 16-byte chunk c of key r sits at chunk c ^ ((r >> 1) & 7),
 //       which makes the 32-row ds_read_b128 fragment reads conflict-free
-//   vt: [d][key] bf16 (V transposed while staged), rows padded to 136 B; the dword holding keys
-//       (2p, 2p+1) of channel d sits at dword p ^ (((d >> 5) & 1) << 3): fragment reads (b64) stay
-//       conflict-free and the transposing ds_write_b32 of one wave drop from 4-way to 2-way
+//   v : [key][64 d] bf16 as it lies in memory, 128-byte rows; chunk c of key r sits at chunk
+//       c ^ (((r >> 1) & 1) << 2).  The V^T operand of O^T = V^T . P^T is fetched with the transposing
+//       read ds_read_b64_tr_b16 (per 16 lanes a block of 4 keys x 16 channels, delivered as 4 keys
+//       of one channel per lane); with that swizzle the four keys of a block fall into four
+//       different bank quarters, so the reads and the 16-byte staging writes are conflict-free
 struct AttnSmem {
     __attribute__((aligned(16))) char k[2][kKTile * 128];
-    __attribute__((aligned(16))) char vt[2][kHead * kVtPitch];
-    __attribute__((aligned(16))) float qe[4][kQeRows * 32];   // per wave: [c][q] = q . E[c]
+    __attribute__((aligned(16))) char v[2][kKTile * 128];
+    __attribute__((aligned(16))) _Float16 qe[4][kQeRows * 32];   // per wave: [c][q] = q . E[c] (fp16: three work-groups fit one CU)
 };
 
-__global__ __launch_bounds__(256, 2) void attention_relkey_kernel(
+__global__ __launch_bounds__(256, 3) void attention_relkey_kernel(
     const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dist_emb,
     const int32_t* __restrict__ lengths, uint16_t* __restrict__ ctx, int t_pad, int n_heads,
     int q_blocks, int left_max, int right_max) {
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void attention_relkey_kernel(
         for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
     }
     // ---- QE^T[c][q] = E[c] . Q[q]: 32-row blocks of the distance table ---------------------------------
-    float* qe = sm.qe[wave];
+    _Float16* qe = sm.qe[wave];
     if (wave_active) {
 #pragma unroll
         for (int cb = 0; cb < kDistRows / 32; ++cb) {
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void attention_relkey_kernel(
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int c = cb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                if (c < kQeRows) qe[c * 32 + r] = acc[e];
+                if (c < kQeRows) qe[c * 32 + r] = (_Float16)acc[e];
             }
         }
     }
@@ -128,8 +129,8 @@ __global__ __launch_bounds__(256, 2) void attention_relkey_kernel(
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    const float bias_left = wave_active ? qe[0 * 32 + r] : 0.f;
-    const float bias_right = wave_active ? qe[(n_dist - 1) * 32 + r] : 0.f;
+    const float bias_left = wave_active ? (float)qe[0 * 32 + r] : 0.f;
+    const float bias_right = wave_active ? (float)qe[(n_dist - 1) * 32 + r] : 0.f;
 
     f32x16 o0, o1, lacc, offv;
 #pragma unroll
@@ -146,49 +147,55 @@ __global__ __launch_bounds__(256, 2) void attention_relkey_kernel(
     for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;   // bf16 1.0
 
     // ---- staging roles ------------------------------------------------------------------------------------
-    // K: thread copies 16-byte chunks (key = tid >> 3 (+32), chunk = tid & 7)
-    // V: thread owns key pair kp = tid >> 3 and channels 8 vch .. 8 vch + 7 (vch = tid & 7)
-    const int kp = tid >> 3, vch = tid & 7;
+    // K and V: thread copies 16-byte chunks (key = tid >> 3 (+32), chunk = tid & 7)
+    const int srow = tid >> 3, schunk = tid & 7;
     const int n_tiles = (len + kKTile - 1) / kKTile;
     const int last_row = t_pad - 1;
-    const int k_lds0 = (tid >> 3) * 128 + (((tid & 7) ^ (((tid >> 3) >> 1) & 7)) << 4);
-    const int k_lds1 = (32 + (tid >> 3)) * 128 + (((tid & 7) ^ (((32 + (tid >> 3)) >> 1) & 7)) << 4);
-    const int vt_lds = (vch * 8) * kVtPitch + ((kp ^ (((vch >> 2) & 1) << 3)) << 2);
+    const int k_lds0 = srow * 128 + ((schunk ^ ((srow >> 1) & 7)) << 4);
+    const int k_lds1 = (32 + srow) * 128 + ((schunk ^ (((32 + srow) >> 1) & 7)) << 4);
+    const int v_lds0 = srow * 128 + ((schunk ^ (((srow >> 1) & 1) << 2)) << 4);
+    const int v_lds1 = v_lds0 + 32 * 128;   // (32 + srow) >> 1 has the same low bit
 
     // named registers (not arrays: an array captured by the lambdas below ends up in scratch memory,
     // which forces a wait right after each global load and defeats the prefetch)
     uint4 kreg0, kreg1, vreg0, vreg1;
+    // Source pointers of this thread's two K rows and two V rows of the tile being requested; they
+    // advance by one tile per load.  Only the last tile can reach past row t_pad - 1: there the row
+    // index is clamped (the keys are masked anyway), everywhere else no address arithmetic is left.
+    const uint16_t* kp0 = base + d_model + schunk * 8 + (int64_t)srow * ld;
+    const uint16_t* vp0 = base + 2 * d_model + schunk * 8 + (int64_t)srow * ld;
+    const int64_t tile_step = (int64_t)kKTile * ld, half_step = (int64_t)32 * ld;
     auto load_tile = [&](int kt) {
-        const int k0 = kt * kKTile;
-        const uint16_t* kb = base + d_model + (tid & 7) * 8;
-        kreg0 = *reinterpret_cast<const uint4*>(kb + min(k0 + (tid >> 3), last_row) * ld);
-        kreg1 = *reinterpret_cast<const uint4*>(kb + min(k0 + 32 + (tid >> 3), last_row) * ld);
-        const uint16_t* vb = base + 2 * d_model + vch * 8;
-        const int key = k0 + 2 * kp;
-        vreg0 = *reinterpret_cast<const uint4*>(vb + min(key, last_row) * ld);
-        vreg1 = *reinterpret_cast<const uint4*>(vb + min(key + 1, last_row) * ld);
+        if ((kt + 1) * kKTile <= t_pad) {
+            kreg0 = *reinterpret_cast<const uint4*>(kp0);
+            kreg1 = *reinterpret_cast<const uint4*>(kp0 + half_step);
+            vreg0 = *reinterpret_cast<const uint4*>(vp0);
+            vreg1 = *reinterpret_cast<const uint4*>(vp0 + half_step);
+        } else {
+            const int k0 = kt * kKTile;
+            const int64_t back0 = (int64_t)(k0 + srow - min(k0 + srow, last_row)) * ld;
+            const int64_t back1 = (int64_t)(k0 + 32 + srow - min(k0 + 32 + srow, last_row)) * ld;
+            kreg0 = *reinterpret_cast<const uint4*>(kp0 - back0);
+            kreg1 = *reinterpret_cast<const uint4*>(kp0 + half_step - back1);
+            vreg0 = *reinterpret_cast<const uint4*>(vp0 - back0);
+            vreg1 = *reinterpret_cast<const uint4*>(vp0 + half_step - back1);
+        }
+        kp0 += tile_step;
+        vp0 += tile_step;
     };
     // `kt` = the tile held in the prefetch registers.  Masked keys (only in the last tile) must not
     // inject non-finite values into P.V: their V rows are zeroed here, after the loads have landed
     // (doing it where the loads are issued would wait for them on the spot).
     auto store_tile = [&](int buf, int kt) {
         if ((kt + 1) * kKTile > len) {
-            const int key = kt * kKTile + 2 * kp;
+            const int key = kt * kKTile + srow;
             if (key >= len) vreg0 = make_uint4(0, 0, 0, 0);
-            if (key + 1 >= len) vreg1 = make_uint4(0, 0, 0, 0);
+            if (key + 32 >= len) vreg1 = make_uint4(0, 0, 0, 0);
         }
         *reinterpret_cast<uint4*>(sm.k[buf] + k_lds0) = kreg0;
         *reinterpret_cast<uint4*>(sm.k[buf] + k_lds1) = kreg1;
-        char* vt = sm.vt[buf] + vt_lds;
-        // channels 8 vch + 2e and + 2e + 1; keys 2 kp and 2 kp + 1 packed into one dword each
-#define OASR_VT_PAIR(E, A, C)                                                                              \
-        *reinterpret_cast<uint32_t*>(vt + (2 * (E)) * kVtPitch) = __builtin_amdgcn_perm((C), (A), 0x05040100); \
-        *reinterpret_cast<uint32_t*>(vt + (2 * (E) + 1) * kVtPitch) = __builtin_amdgcn_perm((C), (A), 0x07060302);
-        OASR_VT_PAIR(0, vreg0.x, vreg1.x)
-        OASR_VT_PAIR(1, vreg0.y, vreg1.y)
-        OASR_VT_PAIR(2, vreg0.z, vreg1.z)
-        OASR_VT_PAIR(3, vreg0.w, vreg1.w)
-#undef OASR_VT_PAIR
+        *reinterpret_cast<uint4*>(sm.v[buf] + v_lds0) = vreg0;
+        *reinterpret_cast<uint4*>(sm.v[buf] + v_lds1) = vreg1;
     };
 
     // K fragment addresses: lane (r, hh) reads key r (+32), logical chunk 2 s + hh
@@ -196,8 +203,18 @@ __global__ __launch_bounds__(256, 2) void attention_relkey_kernel(
 #pragma unroll
     for (int s = 0; s < 4; ++s) k_frag[s] = r * 128 + (((2 * s + hh) ^ ((r >> 1) & 7)) << 4);
     // (32 + r) >> 1 = 16 + (r >> 1): same low three bits, so the second half only adds 32 rows
-    // V^T fragment address of row r (+32): dword 16 u + 8 s2 + 2 hh (+4), swizzled by the row block
-    constexpr int vt_sw0 = 0, vt_sw1 = 8;   // ((row >> 5) & 1) << 3 for rows r and 32 + r
+    // V^T fragments by transposing reads.  In its group of 16 lanes, lane 4 q + p supplies the address
+    // of key (block base + q), channels 16 (g & 1) + 4 p .. + 3, and receives the block's 4 keys of
+    // channel 16 (g & 1) + (lane & 15) = lane & 31 (g = lane >> 4; hh = g >> 1 picks the keys).
+    // Block base of piece w of k-step (u, s2): key 32 u + 16 s2 + 8 w + 4 hh.
+    const int tq = (lane >> 2) & 3, tp = lane & 3, tg = (lane >> 4) & 1;
+    int v_frag[2];   // byte offset inside the tile for db = 0, 1 at key block 0 (key = 4 hh + tq)
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        const int key = 4 * hh + tq;
+        const int cbyte = (32 * db + 16 * tg + 4 * tp) * 2;   // byte offset of the channels inside the row
+        v_frag[db] = key * 128 + ((((cbyte >> 4) ^ (((key >> 1) & 1) << 2)) << 4) | (cbyte & 15));
+    }
 
     load_tile(0);
     store_tile(0, 0);
@@ -221,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void attention_relkey_kernel(
         if (wave_active) {
             const int k0 = kt * kKTile;
             const char* kbuf = sm.k[buf];
-            const char* vbuf = sm.vt[buf];
+            const char* vbuf = sm.v[buf];
             // ---- S^T = K . Q^T for the two 32-key halves (relative to m_run in the FAR case) ---------------
             f32x16 s0, s1;
             if (KIND == FAR) {
@@ -249,8 +266,8 @@ __global__ __launch_bounds__(256, 2) void attention_relkey_kernel(
                     const int krow = (e & 3) + 8 * (e >> 2);
                     const int c0 = min(max(dbase + krow, 0), n_dist - 1);
                     const int c1 = min(max(dbase + krow + 32, 0), n_dist - 1);
-                    const float t0 = s0[e] + (qe[c0 * 32 + r] - m_run);
-                    const float t1 = s1[e] + (qe[c1 * 32 + r] - m_run);
+                    const float t0 = s0[e] + ((float)qe[c0 * 32 + r] - m_run);
+                    const float t1 = s1[e] + ((float)qe[c1 * 32 + r] - m_run);
                     if (KIND == NEAR_MASKED) {
                         const int key = k0 + krow + 4 * hh;
                         s0[e] = key < len ? t0 : -INFINITY;
@@ -263,7 +280,10 @@ __global__ __launch_bounds__(256, 2) void attention_relkey_kernel(
             }
             // ---- raise the running max if needed (always on the first tile) ---------------------------------
             float tmax = max32(s0, s1);
-            tmax = vmax(tmax, __shfl_xor(tmax, 32, 64));
+            {   // the other half of this query's keys lives in lane ^ 32
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+                tmax = vmax(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
             // both lanes of a query (r, r + 32) see the same tmax and m_run: same decision
             const bool raise = first_tile || tmax > kRescaleThreshold;
             if (__builtin_amdgcn_ballot_w64(raise) != 0) {
@@ -300,15 +320,15 @@ __global__ __launch_bounds__(256, 2) void attention_relkey_kernel(
 #pragma unroll
                     for (int j = 0; j < 4; ++j) pw[j] = cvt_pk_bf16(sv[8 * s2 + 2 * j], sv[8 * s2 + 2 * j + 1]);
                     const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
-                    const int dw = 16 * u + 8 * s2 + 2 * hh;   // dword index of the first piece
+                    // key blocks 32 u + 16 s2 + 8 w (+ 4 hh + tq in v_frag): multiples of 8 keep ((key >> 1) & 1)
+                    const int kb_off = (32 * u + 16 * s2) * 128;
 #pragma unroll
                     for (int db = 0; db < 2; ++db) {
-                        const char* vp = vbuf + (32 * db + r) * kVtPitch;
-                        const int sw = db ? vt_sw1 : vt_sw0;
-                        const uint2 va = *reinterpret_cast<const uint2*>(vp + ((dw ^ sw) << 2));
-                        const uint2 vb = *reinterpret_cast<const uint2*>(vp + (((dw + 4) ^ sw) << 2));
-                        u32x4 vw = {va.x, va.y, vb.x, vb.y};
-                        const bf16x8 vf = __builtin_bit_cast(bf16x8, vw);
+                        typedef __attribute__((ext_vector_type(4))) short s16x4;
+                        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+                        const s16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vbuf + kb_off + v_frag[db]));
+                        const s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vbuf + kb_off + 8 * 128 + v_frag[db]));
+                        const bf16x8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
                         if (db == 0)
                             o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o0, 0, 0, 0);
                         else
