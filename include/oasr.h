@@ -220,6 +220,13 @@ int oasr_attention_relkey(const uint16_t* qkv, const uint16_t* dist_emb, const i
 int oasr_dwconv_causal(const uint16_t* x, const float* w, float* y, int32_t batch, int64_t t_pad,
                        int32_t d, int32_t kernel, void* stream);
 
+/* The same convolution followed by LayerNorm over d and Swish, in one pass:
+ * y bf16 [rows][d] = Swish(LayerNorm(conv(x)) * ln_w + ln_b).  d in {512, 1024, 2048}, kernel 31,
+ * t_pad a multiple of 16.  Only rows < batch * t_pad are written. */
+int oasr_dwconv_ln_swish(const uint16_t* x, const float* w, const float* ln_w, const float* ln_b,
+                         uint16_t* y, int32_t batch, int64_t t_pad, int32_t d, int32_t kernel,
+                         float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -132,8 +132,13 @@ int oasr_encoder_forward(const oasr_encoder* enc, const float* feats, const int3
         OASR_TRY(oasr_layernorm(x, w.conv_ln_w, w.conv_ln_b, ws.xn, rows, d, d, c.ln_eps, 1, 0, stream));
         OASR_TRY(oasr_gemm_bf16(ws.xn, w.pw1, nullptr, nullptr, ws.ctx, rows, 2 * (int64_t)d, d, 1.0f,
                                 OASR_EPI_GLU_BF16, stream));
-        OASR_TRY(oasr_dwconv_causal(ws.ctx, w.dw, ws.tmp, batch, t_pad, d, c.conv_kernel, stream));
-        OASR_TRY(oasr_layernorm(ws.tmp, w.dw_ln_w, w.dw_ln_b, ws.xn, live, d, d, c.ln_eps, 1, 1, stream));
+        if (c.conv_kernel == 31 && (d == 512 || d == 1024 || d == 2048) && t_pad % 16 == 0) {
+            OASR_TRY(oasr_dwconv_ln_swish(ws.ctx, w.dw, w.dw_ln_w, w.dw_ln_b, ws.xn, batch, t_pad, d,
+                                          c.conv_kernel, c.ln_eps, stream));
+        } else {
+            OASR_TRY(oasr_dwconv_causal(ws.ctx, w.dw, ws.tmp, batch, t_pad, d, c.conv_kernel, stream));
+            OASR_TRY(oasr_layernorm(ws.tmp, w.dw_ln_w, w.dw_ln_b, ws.xn, live, d, d, c.ln_eps, 1, 1, stream));
+        }
         OASR_TRY(oasr_gemm_bf16(ws.xn, w.pw2, nullptr, x, x, rows, d, d, 1.0f, OASR_EPI_RESIDUAL_F32, stream));
         // half-step feed-forward 2
         OASR_TRY(oasr_layernorm(x, w.ffn2_ln_w, w.ffn2_ln_b, ws.xn, rows, d, d, c.ln_eps, 1, 0, stream));

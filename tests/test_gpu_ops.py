@@ -295,3 +295,31 @@ def test_dwconv_causal(batch, t_pad, d):
     xt = torch.nn.functional.pad(x.double().transpose(1, 2), (30, 0))
     ref = torch.nn.functional.conv1d(xt, w.double()[:, None, :], groups=d).transpose(1, 2)
     torch.testing.assert_close(y.cpu().double().reshape(batch, t_pad, d), ref, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("batch,t_pad,d", [(2, 64, 512), (3, 1504, 1024), (1, 48, 2048)])
+def test_dwconv_ln_swish_fused(batch, t_pad, d):
+    """The fused kernel against float64 conv -> LayerNorm -> Swish, and against the two separate kernels."""
+    H = _lib()
+    g = torch.Generator().manual_seed(d + 1)
+    x = _bf(torch.randn((batch, t_pad, d), generator=g))
+    w = torch.randn((d, 31), generator=g) / math.sqrt(31)
+    ln_w = 1.0 + 0.1 * torch.randn((d,), generator=g)
+    ln_b = 0.1 * torch.randn((d,), generator=g)
+    rows = batch * t_pad
+    xd, wd, lw, lb = x.reshape(-1, d).cuda(), w.t().contiguous().cuda(), ln_w.cuda(), ln_b.cuda()
+    y = torch.zeros((rows, d), dtype=torch.bfloat16, device="cuda")
+    H.check(H.lib().oasr_dwconv_ln_swish(xd.data_ptr(), wd.data_ptr(), lw.data_ptr(), lb.data_ptr(), y.data_ptr(),
+                                         batch, t_pad, d, 31, 1e-5, _stream()))
+    tmp = torch.zeros((rows, d), device="cuda")
+    y2 = torch.zeros((rows, d), dtype=torch.bfloat16, device="cuda")
+    H.check(H.lib().oasr_dwconv_causal(xd.data_ptr(), wd.data_ptr(), tmp.data_ptr(), batch, t_pad, d, 31, _stream()))
+    H.check(H.lib().oasr_layernorm(tmp.data_ptr(), lw.data_ptr(), lb.data_ptr(), y2.data_ptr(), rows, d, d, 1e-5, 1, 1,
+                                   _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)          # same arithmetic in the same order: bit-identical
+    xt = torch.nn.functional.pad(x.double().transpose(1, 2), (30, 0))
+    conv = torch.nn.functional.conv1d(xt, w.double()[:, None, :], groups=d).transpose(1, 2)
+    ref = torch.nn.functional.layer_norm(conv, (d,), ln_w.double(), ln_b.double(), 1e-5)
+    ref = ref * torch.sigmoid(ref)
+    torch.testing.assert_close(y.float().cpu().double().reshape(batch, t_pad, d), ref, atol=2e-2, rtol=1e-2)
