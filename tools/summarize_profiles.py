@@ -17,7 +17,7 @@ prof.mkdir(exist_ok=True)
 
 def one(pattern):
     hits = glob.glob(str(out / pattern), recursive=True)
-    return hits[0] if hits else None
+    return max(hits, key=lambda f: Path(f).stat().st_mtime) if hits else None   # newest run wins
 
 
 def stats_table(mode):
