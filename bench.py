@@ -235,7 +235,8 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": "bf16",
             "data": "synthetic (seeded noise + 440 Hz tone), random-init weights seed 0",
-            "config": {"workload": "BASELINE configs[2]: batch=%d x %.0f s chunks @16 kHz, log-mel + %s encoder "
+            "config": {"workload": ("BASELINE configs[2]" if g.name == "G300" else "geometry of BASELINE configs[4] in bf16") +
+                                   ": batch=%d x %.0f s chunks @16 kHz, log-mel + %s encoder "
                                    "(%d blocks, d=%d, %.0fM params), %s" %
                                    (args.batch, args.seconds, g.name, g.n_layers, g.d_model, g.n_params() / 1e6,
                                     "eager launches" if args.no_graph else "hipGraph-captured step"),

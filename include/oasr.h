@@ -227,6 +227,23 @@ int oasr_dwconv_ln_swish(const uint16_t* x, const float* w, const float* ln_w, c
                          uint16_t* y, int32_t batch, int64_t t_pad, int32_t d, int32_t kernel,
                          float eps, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * CTC output stage (the reference returns text from its remote model,
+ * ref:src/omnilingual_asr/models/inference/gemini_pipeline.py:512-530; here the text comes from a
+ * vocabulary projection of the encoder states, decoded greedily).  The projection itself is
+ * oasr_gemm_bf16 with OASR_EPI_BIAS_F32 on the bf16 copy made by oasr_cast_bf16. */
+
+/* y[i] = bf16(x[i]), round to nearest even; n a multiple of 4. */
+int oasr_cast_bf16(const float* x, uint16_t* y, int64_t n, void* stream);
+
+/* Greedy CTC decode.  logits float32 [batch * t_pad][ld], columns 0..vocab-1 meaningful.  Per
+ * utterance b and frame t < lengths[b]: id = argmax (lowest index on ties); a frame is kept when
+ * id != blank and id differs from the previous frame's id.  tokens / frames int32 [batch][t_pad]
+ * receive the kept ids and their frame indices, -1 past counts[b]. */
+int oasr_ctc_greedy(const float* logits, int64_t ld, int32_t vocab, const int32_t* lengths,
+                    int32_t batch, int64_t t_pad, int32_t blank, int32_t* tokens, int32_t* frames,
+                    int32_t* counts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

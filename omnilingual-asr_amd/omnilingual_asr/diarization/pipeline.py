@@ -66,18 +66,20 @@ class Pipeline:
                    progress_callback: Optional[Callable[[str, int], None]] = None,
                    language: Optional[str] = None, speaker_count: Optional[str] = None,
                    **kwargs) -> List[DiarizedTranscriptSegment]:
-        """Transcribe one file.  `word_timestamps` and unknown keyword arguments are accepted and
-        ignored, `words` is always None (ref diarization/pipeline.py:78-83, :117).  The callback
+        """Transcribe one file.  Unknown keyword arguments are accepted and ignored.  `words` is None
+        as in the reference (ref diarization/pipeline.py:78-83, :117) unless `word_timestamps=True`,
+        which the reference accepts but cannot honour; here it yields the CTC word times.  The callback
         receives ("uploading",0) ("transcribing",1) ("processing",2) ("done",3) on the calling
         thread."""
         result = self.gemini.transcribe_with_retry(
             audio_path, progress_callback=progress_callback, language=language,
-            speaker_count=speaker_count)
+            speaker_count=speaker_count, word_timestamps=bool(word_timestamps))
         self._summary = self._per_thread.summary = result.summary
         self._detected_languages = self._per_thread.languages = result.detected_languages
         return [
             DiarizedTranscriptSegment(
-                start=s.start, end=s.end, speaker=s.speaker, text=s.text, words=None,
+                start=s.start, end=s.end, speaker=s.speaker, text=s.text,
+                words=None if s.words is None else [WordTimestamp(w.word, w.start, w.end) for w in s.words],
                 language=s.language, language_code=s.language_code, languages=s.languages,
                 emotion=s.emotion, translation=s.translation)
             for s in result.segments

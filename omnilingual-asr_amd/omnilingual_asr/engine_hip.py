@@ -13,8 +13,8 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import _hip
-from .weights import Geometry, init_random_weights, pack_for_device, resolve_geometry
+from . import _hip, tokenizer
+from .weights import CTC_LOGIT_PITCH, Geometry, init_random_weights, pack_for_device, resolve_geometry
 
 SAMPLE_RATE = 16000
 
@@ -91,6 +91,12 @@ class HipEngine:
                 "out": torch.zeros((rows, g.d_model), dtype=torch.float32, device=dev),
                 "workspace": torch.zeros((ws_bytes,), dtype=torch.uint8, device=dev),
                 "ws_bytes": ws_bytes,
+                # CTC stage
+                "hid_bf16": torch.zeros((rows, g.d_model), dtype=torch.bfloat16, device=dev),
+                "logits": torch.zeros((rows, CTC_LOGIT_PITCH), dtype=torch.float32, device=dev),
+                "tokens": torch.zeros((batch, t_pad), dtype=torch.int32, device=dev),
+                "tok_frames": torch.zeros((batch, t_pad), dtype=torch.int32, device=dev),
+                "counts": torch.zeros((batch,), dtype=torch.int32, device=dev),
             }
             self._buffers[key] = buf
         return buf
@@ -125,6 +131,29 @@ class HipEngine:
             _hip.current_stream_ptr()), "oasr_encoder_forward")
         g = self.geometry
         return buf["out"][: batch * t_pad].view(batch, t_pad, g.d_model)
+
+    def decode(self, hidden: torch.Tensor, lengths: torch.Tensor, buf=None):
+        """Encoder states float32 [B, t_pad, d] (as returned by `encode_features`) and lengths int32 [B]
+        -> (tokens int32 [B, t_pad], frames int32 [B, t_pad], counts int32 [B]) on the device: vocabulary
+        projection (bf16 GEMM, float32 logits) and greedy CTC decoding."""
+        if "ctc_w" not in self._packed:
+            raise _hip.OasrError("this weight set has no CTC head")
+        batch, t_pad, d = hidden.shape
+        if buf is None:
+            buf = self._get_buffers(batch, 160 * (2 * t_pad - 1) + 400)
+        rows = buf["rows"]
+        L, st = _hip.lib(), _hip.current_stream_ptr()
+        if hidden.data_ptr() != buf["out"].data_ptr():
+            buf["out"][: batch * t_pad].copy_(hidden.reshape(batch * t_pad, d))
+        _hip.check(L.oasr_cast_bf16(buf["out"].data_ptr(), buf["hid_bf16"].data_ptr(), rows * d, st), "oasr_cast_bf16")
+        _hip.check(L.oasr_gemm_bf16(buf["hid_bf16"].data_ptr(), self._packed["ctc_w"].data_ptr(),
+                                    self._packed["ctc_b"].data_ptr(), None, buf["logits"].data_ptr(), rows,
+                                    CTC_LOGIT_PITCH, d, 1.0, _hip.EPI_BIAS_F32, st), "oasr_gemm_bf16 (ctc)")
+        _hip.check(L.oasr_ctc_greedy(buf["logits"].data_ptr(), CTC_LOGIT_PITCH, self.geometry.vocab_size,
+                                     _hip._ptr(lengths, torch.int32), batch, t_pad, tokenizer.BLANK,
+                                     buf["tokens"].data_ptr(), buf["tok_frames"].data_ptr(),
+                                     buf["counts"].data_ptr(), st), "oasr_ctc_greedy")
+        return buf["tokens"], buf["tok_frames"], buf["counts"]
 
     def step(self, pcm: torch.Tensor, n_valid: torch.Tensor):
         """One pass of the whole device path over one resident batch (eager launches)."""
@@ -163,3 +192,20 @@ class HipEngine:
         with torch.cuda.device(self.device):
             hidden, lengths = self.step(pcm_d, nv)
             return hidden, lengths.cpu().numpy()
+
+    def transcribe_batch(self, pcm, n_valid):
+        """`encode_batch` plus the CTC stage.  Returns (hidden, lengths, tokens) where tokens is a list
+        of (ids int32 array, frame-index int32 array) per utterance, on the host."""
+        pcm_t = torch.as_tensor(pcm, dtype=torch.float32)
+        if pcm_t.dim() != 2:
+            raise ValueError("pcm must be [batch, samples]")
+        if pcm_t.shape[1] % 4:
+            pcm_t = torch.nn.functional.pad(pcm_t, (0, 4 - pcm_t.shape[1] % 4))
+        pcm_d = pcm_t.to(self.device, non_blocking=True).contiguous()
+        nv = torch.as_tensor(np.asarray(n_valid, dtype=np.int32)).to(self.device)
+        with torch.cuda.device(self.device):
+            hidden, lengths = self.step(pcm_d, nv)
+            tok, frm, cnt = self.decode(hidden, lengths)
+            tok_h, frm_h, cnt_h = tok.cpu().numpy(), frm.cpu().numpy(), cnt.cpu().numpy()
+            out = [(tok_h[i, : cnt_h[i]].copy(), frm_h[i, : cnt_h[i]].copy()) for i in range(tok_h.shape[0])]
+            return hidden, lengths.cpu().numpy(), out

@@ -20,6 +20,7 @@ from typing import Any, Callable, List, Optional, Sequence
 import numpy as np
 
 from omnilingual_asr import audio as _audio
+from omnilingual_asr import tokenizer as _tok
 
 SAMPLE_RATE = 16000
 
@@ -199,7 +200,9 @@ def offset_result(result: GeminiTranscriptionResult, start_offset: float) -> Gem
     shifted = [GeminiTranscriptSegment(
         start=s.start + start_offset, end=s.end + start_offset, speaker=s.speaker, text=s.text,
         language=s.language, language_code=s.language_code, emotion=s.emotion,
-        translation=s.translation, words=s.words) for s in result.segments]
+        translation=s.translation,
+        words=None if s.words is None else [WordTimestamp(w.word, w.start + start_offset, w.end + start_offset)
+                                            for w in s.words]) for s in result.segments]
     return GeminiTranscriptionResult(summary=result.summary, segments=shifted,
                                      detected_languages=result.detected_languages)
 
@@ -229,16 +232,25 @@ class ChunkRecord:
     chunk_idx: int
     start_sample: int
     end_sample: int
-    n_frames: int          # valid encoder frames (40 ms each)
+    n_frames: int          # valid encoder frames (20 ms each)
     activity: float        # mean |encoder state| over the valid frames
+    tokens: Optional[np.ndarray] = None   # greedy CTC token ids (int32), None when the engine has no head
+    frames: Optional[np.ndarray] = None   # encoder frame index of each token
 
-    def to_result(self, sample_rate: int = SAMPLE_RATE) -> GeminiTranscriptionResult:
-        """Chunk-local result: one segment spanning the chunk.  No decoder head exists yet, so `text`
-        is empty; speaker and emotion take the reference's defaults (ref :435, :440)."""
+    def to_result(self, sample_rate: int = SAMPLE_RATE, word_timestamps: bool = False) -> GeminiTranscriptionResult:
+        """Chunk-local result: one segment spanning the chunk with the decoded text (empty when the
+        engine has no CTC head); speaker and emotion take the reference's defaults (ref :435, :440).
+        `words` stays None unless asked for, as in the reference (ref diarization/pipeline.py:117)."""
         dur = (self.end_sample - self.start_sample) / float(sample_rate)
         end = dur if dur > 0.0 else 1.0          # the reference's end<=start fix-up (ref :396-397)
-        seg = GeminiTranscriptSegment(start=0.0, end=end, speaker="Speaker 1", text="",
-                                      emotion="neutral", words=None)
+        text, words = "", None
+        if self.tokens is not None:
+            text = _tok.decode_text(self.tokens)
+            if word_timestamps:
+                words = [WordTimestamp(word=w, start=f0 * _tok.FRAME_SECONDS, end=f1 * _tok.FRAME_SECONDS)
+                         for w, f0, f1 in _tok.words_with_frames(self.tokens, self.frames)]
+        seg = GeminiTranscriptSegment(start=0.0, end=end, speaker="Speaker 1", text=text,
+                                      emotion="neutral", words=words)
         return GeminiTranscriptionResult(summary=None, segments=[seg], detected_languages=None)
 
 
@@ -288,19 +300,24 @@ class GeminiASRPipeline:
             n_valid = [int(e - s) for s, e in part]
             try:
                 with self._engine_lock:
-                    hidden, lengths = self.engine.encode_batch(batch, n_valid)
+                    if hasattr(self.engine, "transcribe_batch"):
+                        hidden, lengths, toks = self.engine.transcribe_batch(batch, n_valid)
+                    else:
+                        hidden, lengths = self.engine.encode_batch(batch, n_valid)
+                        toks = [(None, None)] * len(part)
                     acts = _mean_abs(hidden, lengths)
             except Exception as exc:  # per-batch failure is tolerated, as per-chunk failure is in
                 print(f"Chunk transcription failed: {exc}")   # the reference (ref :635-641)
                 continue
             for i, (s, e) in enumerate(part):
-                records.append(ChunkRecord(first_idx + lo + i, int(s), int(e), int(lengths[i]), float(acts[i])))
+                records.append(ChunkRecord(first_idx + lo + i, int(s), int(e), int(lengths[i]), float(acts[i]),
+                                           toks[i][0], toks[i][1]))
         return records
 
     # ---- single-utterance path (ref :474-539) -----------------------------------------------------------
     def transcribe(self, audio_path, *, progress_callback: Optional[Callable[[str, int], None]] = None,
                    language: Optional[str] = None, speaker_count: Optional[str] = None,
-                   ) -> GeminiTranscriptionResult:
+                   word_timestamps: bool = False) -> GeminiTranscriptionResult:
         def report(step, idx):
             if progress_callback:
                 progress_callback(step, idx)
@@ -313,18 +330,19 @@ class GeminiASRPipeline:
         if not with_state:
             raise RuntimeError("encoder produced no output for " + str(audio_path))
         report("processing", 2)
-        result = with_state[0].to_result()
+        result = with_state[0].to_result(word_timestamps=word_timestamps)
         report("done", 3)
         return result
 
-    def _transcribe_chunk(self, record: ChunkRecord) -> GeminiTranscriptionResult:
+    def _transcribe_chunk(self, record: ChunkRecord, word_timestamps: bool = False) -> GeminiTranscriptionResult:
         """Chunk-local result shifted to file time (ref :541-575)."""
-        return offset_result(record.to_result(), record.start_sample / float(SAMPLE_RATE))
+        return offset_result(record.to_result(word_timestamps=word_timestamps),
+                             record.start_sample / float(SAMPLE_RATE))
 
     # ---- long-audio path (ref :577-682) -----------------------------------------------------------------
     def transcribe_chunked(self, audio_path, *, progress_callback: Optional[Callable[[str, int], None]] = None,
                            language: Optional[str] = None, speaker_count: Optional[str] = None,
-                           ) -> GeminiTranscriptionResult:
+                           word_timestamps: bool = False) -> GeminiTranscriptionResult:
         def report(step, idx):
             if progress_callback:
                 progress_callback(step, idx)
@@ -335,7 +353,8 @@ class GeminiASRPipeline:
         if len(bounds) <= 1:
             # same fall-through as the reference (ref :609-616), including its repeated progress steps
             return self.transcribe(audio_path, progress_callback=progress_callback,
-                                   language=language, speaker_count=speaker_count)
+                                   language=language, speaker_count=speaker_count,
+                                   word_timestamps=word_timestamps)
         report("transcribing", 1)
         if self.process_group is not None:
             from omnilingual_asr import distributed as _dist
@@ -343,7 +362,7 @@ class GeminiASRPipeline:
         else:
             records = self._encode_chunks(pcm, bounds)
         report("processing", 2)
-        merged = merge_results([self._transcribe_chunk(r) for r in records])
+        merged = merge_results([self._transcribe_chunk(r, word_timestamps) for r in records])
         report("done", 3)
         return merged
 
@@ -351,7 +370,7 @@ class GeminiASRPipeline:
     def transcribe_with_retry(self, audio_path, *, max_retries: int = 3,
                               progress_callback: Optional[Callable[[str, int], None]] = None,
                               language: Optional[str] = None, speaker_count: Optional[str] = None,
-                              ) -> GeminiTranscriptionResult:
+                              word_timestamps: bool = False) -> GeminiTranscriptionResult:
         import time
 
         audio_path = Path(audio_path)
@@ -361,7 +380,7 @@ class GeminiASRPipeline:
         for attempt in range(max_retries):
             try:
                 return run(audio_path, progress_callback=progress_callback, language=language,
-                           speaker_count=speaker_count)
+                           speaker_count=speaker_count, word_timestamps=word_timestamps)
             except Exception as exc:
                 last_error = exc
                 if attempt < max_retries - 1:

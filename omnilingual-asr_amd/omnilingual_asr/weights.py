@@ -3,7 +3,7 @@
 The reference ships no weights (recognition is remote,
 ref:src/omnilingual_asr/models/inference/gemini_pipeline.py:512-530), so geometries are declared
 here and weights are random-initialised from a seed.  A weight set is a dict
-`{'fp_ln_w', 'fp_ln_b', 'fp_w', 'fp_b', 'layers': [ {...} ]}` of float32 CPU tensors in the
+`{'fp_ln_w', 'fp_ln_b', 'fp_w', 'fp_b', 'layers': [ {...} ], 'ctc_w', 'ctc_b'}` of float32 CPU tensors in the
 natural (Linear `[out, in]`) layout; `pack_for_device` converts it to what liboasr_hip.so reads.
 """
 
@@ -27,6 +27,7 @@ class Geometry:
     left_max: int = 64
     right_max: int = 8
     ln_eps: float = 1e-5
+    vocab_size: int = 32          # CTC head outputs (tokenizer.VOCAB_SIZE)
 
     @property
     def head_dim(self) -> int:
@@ -110,6 +111,8 @@ def init_random_weights(g: Geometry, seed: int = 0, ln_jitter: float = 0.1) -> d
         L["final_ln_w"], L["final_ln_b"] = ln(d)
         layers.append({k: L[k] for k in LAYER_KEYS})
     w["layers"] = layers
+    # CTC head, drawn last so that the encoder weights of a seed do not depend on it
+    w["ctc_w"], w["ctc_b"] = lin(g.vocab_size, d)
     return w
 
 
@@ -121,6 +124,8 @@ def glu_interleave(pw1: torch.Tensor) -> torch.Tensor:
     gate = pw1[d:].reshape(d // 16, 16, -1)
     return torch.cat([val, gate], dim=1).reshape(2 * d, -1).contiguous()
 
+
+CTC_LOGIT_PITCH = 256   # columns of the logits matrix (one GEMM tile)
 
 # log2(e): `oasr_attention_relkey` works in log2 units and expects q * log2(e) / sqrt(head_dim)
 ATTENTION_Q_SCALE = 1.4426950408889634
@@ -155,4 +160,13 @@ def pack_for_device(weights: dict, g: Geometry, device) -> dict:
         for n in ("ffn1_ln", "attn_ln", "conv_ln", "dw_ln", "ffn2_ln", "final_ln"):
             P[n + "_w"], P[n + "_b"] = f32(L[n + "_w"]), f32(L[n + "_b"])
         layers.append(P)
-    return {"top": top, "layers": layers}
+    packed = {"top": top, "layers": layers}
+    if "ctc_w" in weights:
+        # vocabulary projection padded to one 256-column GEMM tile; padded outputs can never win the argmax
+        v = weights["ctc_w"].shape[0]
+        cw = torch.zeros((CTC_LOGIT_PITCH, g.d_model), dtype=torch.float32)
+        cw[:v] = weights["ctc_w"]
+        cb = torch.full((CTC_LOGIT_PITCH,), -1e30, dtype=torch.float32)
+        cb[:v] = weights["ctc_b"]
+        packed["ctc_w"], packed["ctc_b"] = bf(cw), f32(cb)
+    return packed

@@ -11,7 +11,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from . import conformer, logmel
+from . import conformer, ctc, logmel
 
 
 class OracleEngine:
@@ -34,3 +34,8 @@ class OracleEngine:
         hidden = conformer.forward(torch.from_numpy(feats), torch.from_numpy(lengths), w, self.geometry,
                                    dtype=self.dtype)
         return hidden.to(torch.float32), lengths
+
+    def transcribe_batch(self, pcm, n_valid):
+        hidden, lengths = self.encode_batch(pcm, n_valid)
+        lg = ctc.logits(hidden, self.weights["ctc_w"], self.weights["ctc_b"]).numpy()
+        return hidden, lengths, ctc.greedy(lg, lengths, blank=0)
