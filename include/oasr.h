@@ -244,6 +244,19 @@ int oasr_ctc_greedy(const float* logits, int64_t ld, int32_t vocab, const int32_
                     int32_t batch, int64_t t_pad, int32_t blank, int32_t* tokens, int32_t* frames,
                     int32_t* counts, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Sample-rate conversion to 16 kHz on the device.  The reference sends the file as it is to its
+ * remote model (ref:src/omnilingual_asr/models/inference/gemini_pipeline.py:339-362) and its sample
+ * file is 22.05 kHz; the local front end needs 16 kHz.
+ *
+ * y[n] = sum_{j<taps} hp[(n*down+half) % up][j] * x[(n*down+half)/up - j], x = 0 outside [0, n_in).
+ * hp float64 [up][taps] = polyphase branches of the low-pass filter (host-built), x float32
+ * [batch][x_stride], y float32 [batch][y_stride], n_out = oasr_resample_length(n_in, up, down). */
+int64_t oasr_resample_length(int64_t n_in, int32_t up, int32_t down);
+int oasr_resample_poly(const float* x, int64_t n_in, int64_t x_stride, int32_t batch,
+                       const double* hp, int32_t up, int32_t down, int32_t taps, int32_t half,
+                       float* y, int64_t n_out, int64_t y_stride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,65 @@
+// Rational polyphase resampler for gfx950:
+//   y[n] = sum_{j < taps} hp[phase(n)][j] * x[k_hi(n) - j],
+//   pos = n * down + half,  phase = pos % up,  k_hi = pos / up,   x[k] = 0 outside 0 <= k < n_in,
+// where hp[p][j] = h[p + j * up] are the polyphase branches of the low-pass h (built by the host in
+// float64).  A thread produces one output sample: its `taps` inputs are consecutive (neighbouring
+// outputs overlap, so they come from L1/L2) and its coefficients are one row of the branch table
+// (tens of kilobytes, cache resident).  Accumulation is float64 so that the float32 result equals the
+// host implementation's to the last bit or one unit in the last place.  HBM-bound: n_in * 4 bytes
+// in, n_out * 4 bytes out per signal.
+#include "oasr_common.h"
+
+namespace oasr {
+
+__global__ __launch_bounds__(256) void resample_poly_kernel(const float* __restrict__ x, int64_t n_in,
+                                                            int64_t x_stride, const double* __restrict__ hp,
+                                                            int up, int down, int taps, int half,
+                                                            float* __restrict__ y, int64_t n_out,
+                                                            int64_t y_stride) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= n_out) return;
+    const float* xs = x + (int64_t)blockIdx.y * x_stride;
+    const int64_t pos = n * down + half;
+    const int phase = (int)(pos % up);
+    const int64_t k_hi = pos / up;
+    const double* c = hp + (int64_t)phase * taps;
+    double acc = 0.0;
+    if (k_hi - (taps - 1) >= 0 && k_hi < n_in) {
+        for (int j = 0; j < taps; ++j) acc = fma(c[j], (double)xs[k_hi - j], acc);
+    } else {
+        for (int j = 0; j < taps; ++j) {
+            const int64_t k = k_hi - j;
+            if (k >= 0 && k < n_in) acc = fma(c[j], (double)xs[k], acc);
+        }
+    }
+    y[(int64_t)blockIdx.y * y_stride + n] = (float)acc;
+}
+
+}  // namespace oasr
+
+using namespace oasr;
+
+extern "C" int64_t oasr_resample_length(int64_t n_in, int32_t up, int32_t down) {
+    if (n_in < 0 || up <= 0 || down <= 0) return -1;
+    return (n_in * up + down - 1) / down;
+}
+
+extern "C" int oasr_resample_poly(const float* x, int64_t n_in, int64_t x_stride, int32_t batch,
+                                  const double* hp, int32_t up, int32_t down, int32_t taps,
+                                  int32_t half, float* y, int64_t n_out, int64_t y_stride,
+                                  void* stream) {
+    OASR_REQUIRE(x && hp && y, "resample: null pointer");
+    OASR_REQUIRE(batch > 0 && batch <= 65535, "resample: bad batch");
+    OASR_REQUIRE(up > 0 && down > 0 && taps > 0 && half >= 0, "resample: bad up/down/taps/half");
+    OASR_REQUIRE(n_in >= 0 && x_stride >= n_in && y_stride >= n_out, "resample: strides shorter than the signals");
+    OASR_REQUIRE(n_out == oasr_resample_length(n_in, up, down), "resample: n_out must be ceil(n_in * up / down) = %lld",
+                 (long long)oasr_resample_length(n_in, up, down));
+    OASR_REQUIRE(n_in < ((int64_t)1 << 40), "resample: signal too long");
+    if (n_out == 0) return OASR_OK;
+    const int64_t blocks = (n_out + 255) / 256;
+    OASR_REQUIRE(blocks < ((int64_t)1 << 31), "resample: too many output samples per launch");
+    hipLaunchKernelGGL(resample_poly_kernel, dim3((unsigned)blocks, (unsigned)batch), dim3(256), 0,
+                       (hipStream_t)stream, x, n_in, x_stride, hp, up, down, taps, half, y, n_out, y_stride);
+    OASR_CHECK_LAUNCH("resample");
+    return OASR_OK;
+}

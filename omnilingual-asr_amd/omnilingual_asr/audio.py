@@ -108,6 +108,21 @@ def resample_filter(up: int, down: int, half_width: int = 10, beta: float = 5.0)
     return h / h.sum() * up
 
 
+def polyphase_branches(rate_in: int, rate_out: int = TARGET_RATE):
+    """(up, down, half, hp) with hp[p, j] = h[p + j * up], float64 [up, taps]: the table both the host
+    resampler below and the device kernel (`oasr_resample_poly`) read."""
+    fr = Fraction(rate_out, rate_in)
+    up, down = fr.numerator, fr.denominator
+    h = resample_filter(up, down)
+    half = (len(h) - 1) // 2
+    taps = -(-len(h) // up)
+    hp = np.zeros((up, taps), dtype=np.float64)
+    for p in range(up):
+        seg = h[p::up]
+        hp[p, : len(seg)] = seg
+    return up, down, half, hp
+
+
 def resample_poly(x: np.ndarray, rate_in: int, rate_out: int = TARGET_RATE) -> np.ndarray:
     """Rational polyphase resampler: y[n] = sum_k x[k] h[n*down - k*up + half], output length
     ceil(len(x) * up / down).  float64 accumulate, float32 result."""
@@ -138,8 +153,11 @@ def resample_poly(x: np.ndarray, rate_in: int, rate_out: int = TARGET_RATE) -> n
     return y.astype(np.float32)
 
 
-def load_audio_16k(path) -> np.ndarray:
-    """File -> mono float32 at 16 kHz (channels averaged)."""
+def load_audio_16k(path, resampler=None) -> np.ndarray:
+    """File -> mono float32 at 16 kHz (channels averaged).  `resampler(mono, rate) -> float32 array`
+    replaces the host polyphase filter when given (the device engine passes its own)."""
     x, rate = read_wav(path)
     mono = x.mean(axis=1, dtype=np.float64) if x.shape[1] > 1 else x[:, 0]
+    if resampler is not None and rate != TARGET_RATE:
+        return np.asarray(resampler(np.asarray(mono, dtype=np.float32), rate), dtype=np.float32)
     return resample_poly(mono, rate, TARGET_RATE)

@@ -42,6 +42,7 @@ class HipEngine:
         self._handle = self._create_handle()
         self._buffers: dict = {}
         self._graphs: dict = {}
+        self._resample_tables: dict = {}
         self.use_graphs = use_graphs
 
     # ---- set-up ---------------------------------------------------------------------------------------
@@ -131,6 +132,34 @@ class HipEngine:
             _hip.current_stream_ptr()), "oasr_encoder_forward")
         g = self.geometry
         return buf["out"][: batch * t_pad].view(batch, t_pad, g.d_model)
+
+    def resample_16k(self, x, rate_in: int) -> torch.Tensor:
+        """Mono float32 signal(s) [N] or [B, N] at `rate_in` (host array or device tensor) -> float32
+        device tensor at 16 kHz, by the polyphase kernel with the host-designed low-pass."""
+        from . import audio as _audio
+        xt = torch.as_tensor(x, dtype=torch.float32)
+        squeeze = xt.dim() == 1
+        if squeeze:
+            xt = xt[None, :]
+        xd = xt.to(self.device).contiguous()
+        if int(rate_in) == SAMPLE_RATE:
+            return xd[0] if squeeze else xd
+        key = int(rate_in)
+        tab = self._resample_tables.get(key)
+        if tab is None:
+            up, down, half, hp = _audio.polyphase_branches(key, SAMPLE_RATE)
+            tab = (up, down, half, torch.from_numpy(hp).to(self.device))
+            self._resample_tables[key] = tab
+        up, down, half, hp = tab
+        batch, n_in = xd.shape
+        L = _hip.lib()
+        n_out = int(L.oasr_resample_length(n_in, up, down))
+        y = torch.empty((batch, n_out), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _hip.check(L.oasr_resample_poly(xd.data_ptr(), n_in, n_in, batch, hp.data_ptr(), up, down, hp.shape[1],
+                                            half, y.data_ptr(), n_out, n_out, _hip.current_stream_ptr()),
+                       "oasr_resample_poly")
+        return y[0] if squeeze else y
 
     def decode(self, hidden: torch.Tensor, lengths: torch.Tensor, buf=None):
         """Encoder states float32 [B, t_pad, d] (as returned by `encode_features`) and lengths int32 [B]

@@ -314,6 +314,15 @@ class GeminiASRPipeline:
                                            toks[i][0], toks[i][1]))
         return records
 
+    def _load_audio(self, audio_path) -> np.ndarray:
+        """Mono float32 at 16 kHz; the rate conversion runs on the device when the engine offers it."""
+        resampler = None
+        if hasattr(self.engine, "resample_16k"):
+            def resampler(mono, rate):
+                with self._engine_lock:
+                    return self.engine.resample_16k(mono, rate).cpu().numpy()
+        return _audio.load_audio_16k(Path(audio_path), resampler)
+
     # ---- single-utterance path (ref :474-539) -----------------------------------------------------------
     def transcribe(self, audio_path, *, progress_callback: Optional[Callable[[str, int], None]] = None,
                    language: Optional[str] = None, speaker_count: Optional[str] = None,
@@ -323,7 +332,7 @@ class GeminiASRPipeline:
                 progress_callback(step, idx)
 
         report("uploading", 0)
-        pcm = _audio.load_audio_16k(Path(audio_path))
+        pcm = self._load_audio(audio_path)
         report("transcribing", 1)
         bounds = np.array([[0, pcm.shape[0]]], dtype=np.int64)
         with_state = self._encode_chunks(pcm, bounds)
@@ -348,7 +357,7 @@ class GeminiASRPipeline:
                 progress_callback(step, idx)
 
         report("uploading", 0)
-        pcm = _audio.load_audio_16k(Path(audio_path))
+        pcm = self._load_audio(audio_path)
         bounds = plan_chunks(pcm.shape[0], self.chunk_seconds, self.min_chunking_seconds)
         if len(bounds) <= 1:
             # same fall-through as the reference (ref :609-616), including its repeated progress steps

@@ -1,0 +1,48 @@
+"""GPU test of the device polyphase resampler through the C ABI, against the host implementation
+(which tests/test_audio.py pins to scipy.signal.resample_poly)."""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("rate_in,n_in", [(22050, 387574), (44100, 100001), (48000, 48000), (8000, 12345),
+                                          (11025, 5), (32000, 1)])
+def test_resample_matches_host(rate_in, n_in):
+    from omnilingual_asr import audio
+    from omnilingual_asr.engine_hip import HipEngine
+
+    eng = HipEngine("GTINY")
+    rng = np.random.default_rng(rate_in)
+    x = (0.3 * rng.standard_normal((2, n_in))).astype(np.float32)
+    y = eng.resample_16k(x, rate_in).cpu().numpy()
+    for b in range(2):
+        ref = audio.resample_poly(x[b], rate_in)
+        assert y[b].shape == ref.shape                       # integer length: exact
+        np.testing.assert_allclose(y[b], ref, rtol=0, atol=1.2e-7)   # float64 accumulate on both sides: <= 1 ulp of 1.0
+    one = eng.resample_16k(x[0], rate_in)
+    assert one.dim() == 1 and torch.equal(one.cpu(), torch.from_numpy(y[0]))
+
+
+def test_resample_length_and_argument_checks():
+    from omnilingual_asr import _hip
+    L = _hip.lib()
+    assert L.oasr_resample_length(387574, 320, 441) == 281233     # the reference's sample file at 16 kHz
+    assert L.oasr_resample_length(0, 1, 3) == 0 and L.oasr_resample_length(-1, 1, 3) == -1
+    z = torch.zeros((8,), device="cuda")
+    h = torch.zeros((4,), dtype=torch.float64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert L.oasr_resample_poly(z.data_ptr(), 8, 8, 1, h.data_ptr(), 1, 2, 4, 1, z.data_ptr(), 5, 8, st) == -1
+    assert b"n_out" in L.oasr_last_error()
+
+
+def test_pipeline_uses_device_resampler(golden_dir):
+    from omnilingual_asr import Pipeline, audio
+
+    pipe = Pipeline(model="GTINY", seed=4)
+    got = pipe.gemini._load_audio(golden_dir / "gettysburg.wav")
+    ref = audio.load_audio_16k(golden_dir / "gettysburg.wav")
+    assert got.shape == ref.shape == (281233,)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1.2e-7)
