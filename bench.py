@@ -166,6 +166,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--seconds", type=float, default=30.0)
     ap.add_argument("--model", default="G300")
+    ap.add_argument("--fp8", action="store_true", help="e4m3 weights and activations in the large projections")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -193,7 +194,7 @@ def main() -> None:
     from omnilingual_asr.models.inference.asr_pipeline import ChunkRecord
     from omnilingual_asr import _hip
 
-    engine = HipEngine(args.model, seed=0)
+    engine = HipEngine(args.model, seed=0, fp8=args.fp8)
     g = engine.geometry
     n = int(args.seconds * 16000)
     dev = engine.device
@@ -241,9 +242,9 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16",
+            "dtype": "fp8 (e4m3) projections, bf16 elsewhere" if args.fp8 else "bf16",
             "data": "synthetic (seeded noise + 440 Hz tone), random-init weights seed 0",
-            "config": {"workload": ("BASELINE configs[2]" if g.name == "G300" else "geometry of BASELINE configs[4] in bf16") +
+            "config": {"workload": ("BASELINE configs[2]" if g.name == "G300" else "geometry of BASELINE configs[4]") + (" fp8" if args.fp8 else "") +
                                    ": batch=%d x %.0f s chunks @16 kHz, log-mel + %s encoder "
                                    "(%d blocks, d=%d, %.0fM params), %s" %
                                    (args.batch, args.seconds, g.name, g.n_layers, g.d_model, g.n_params() / 1e6,

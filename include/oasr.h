@@ -160,6 +160,24 @@ int oasr_encoder_create(const oasr_encoder_config* cfg, const oasr_top_weights* 
                         const oasr_layer_weights* layers, oasr_encoder** out);
 void oasr_encoder_destroy(oasr_encoder* enc);
 
+/* Optional fp8 (OCP e4m3) weights for the eight large projections of every block: q = e4m3 bytes in
+ * the layout of the bf16 matrix ([out][in]; pw1 GLU-interleaved, q rows of wqkv pre-scaled), s =
+ * float32 scale per output row (weight = q * s).  After this call the forward quantises each
+ * projection's bf16 input per row (oasr_quant_fp8_rows) and runs oasr_gemm_fp8; the input
+ * projection and everything else stay as they are.  Call before oasr_encoder_workspace_bytes (the
+ * workspace grows by the quantised operand).  Passing NULL returns to bf16. */
+typedef struct oasr_layer_fp8_weights {
+    const uint8_t* ffn1_w1_q; const float* ffn1_w1_s;
+    const uint8_t* ffn1_w2_q; const float* ffn1_w2_s;
+    const uint8_t* wqkv_q;    const float* wqkv_s;
+    const uint8_t* wo_q;      const float* wo_s;
+    const uint8_t* pw1_q;     const float* pw1_s;
+    const uint8_t* pw2_q;     const float* pw2_s;
+    const uint8_t* ffn2_w1_q; const float* ffn2_w1_s;
+    const uint8_t* ffn2_w2_q; const float* ffn2_w2_s;
+} oasr_layer_fp8_weights;
+int oasr_encoder_set_fp8(oasr_encoder* enc, const oasr_layer_fp8_weights* layers);
+
 /* Rows of the activation matrices for a batch: round_up(batch * t_pad, 256). */
 int64_t oasr_encoder_rows(int32_t batch, int64_t t_pad);
 /* Bytes of caller-provided device workspace for oasr_encoder_forward. */
@@ -206,6 +224,17 @@ typedef enum oasr_epilogue {
 int oasr_gemm_bf16(const uint16_t* a, const uint16_t* w, const float* bias, const float* resid,
                    void* c, int64_t m, int64_t n, int64_t k, float alpha, int32_t epilogue,
                    void* stream);
+
+/* fp8 path (OCP e4m3).  y[r][:] = e4m3(x[r][:] / scale[r]), scale[r] = max|x[r]| / 448 (1 for an
+ * all-zero row); x bf16 [rows][k], k a multiple of 8. */
+int oasr_quant_fp8_rows(const uint16_t* x, int64_t rows, int64_t k, uint8_t* y, float* scale,
+                        void* stream);
+
+/* C[m][n] = epilogue(scale_a[m] * scale_w[n] * sum_k A8[m][k] * W8[n][k]): the fp8 counterpart of
+ * oasr_gemm_bf16 (same epilogues and shape rules); A8, W8 e4m3 bytes, scales float32. */
+int oasr_gemm_fp8(const uint8_t* a, const uint8_t* w, const float* scale_a, const float* scale_w,
+                  const float* bias, const float* resid, void* c, int64_t m, int64_t n, int64_t k,
+                  float alpha, int32_t epilogue, void* stream);
 
 /* Multi-head self-attention with clamped relative-key bias and key-length masking.
  * qkv bf16 [rows][3*d] (q | k | v), ctx bf16 [rows][d]; head size 64.  The kernel works in log2

@@ -10,6 +10,7 @@ struct oasr_encoder {
     oasr_encoder_config cfg;
     oasr_top_weights top;
     std::vector<oasr_layer_weights> layers;
+    std::vector<oasr_layer_fp8_weights> fp8;   // empty: bf16 projections
 };
 
 namespace oasr {
@@ -21,10 +22,12 @@ struct Workspace {
     uint16_t* big;  // [rows][max(ffn, 3d)]  FFN hidden / fused qkv / padded features
     uint16_t* ctx;  // [rows][d]      attention context / GLU output
     float* tmp;     // [rows][d]      depthwise-conv output
+    uint8_t* a8;    // [rows][max(ffn, d)]  e4m3 copy of the projection input (fp8 mode only)
+    float* sa;      // [rows]               its row scales
     int64_t bytes;
 };
 
-static Workspace carve(const oasr_encoder_config& c, int64_t rows, char* base) {
+static Workspace carve(const oasr_encoder_config& c, int64_t rows, char* base, bool fp8) {
     Workspace w;
     const int64_t wide = c.ffn_dim > 3 * c.d_model ? c.ffn_dim : 3 * c.d_model;
     int64_t off = 0;
@@ -37,6 +40,12 @@ static Workspace carve(const oasr_encoder_config& c, int64_t rows, char* base) {
     w.big = reinterpret_cast<uint16_t*>(take(rows * wide * 2));
     w.ctx = reinterpret_cast<uint16_t*>(take(rows * c.d_model * 2));
     w.tmp = reinterpret_cast<float*>(take(rows * c.d_model * 4));
+    w.a8 = nullptr;
+    w.sa = nullptr;
+    if (fp8) {
+        w.a8 = reinterpret_cast<uint8_t*>(take(rows * (c.ffn_dim > c.d_model ? c.ffn_dim : c.d_model)));
+        w.sa = reinterpret_cast<float*>(take(rows * 4));
+    }
     w.bytes = off;
     return w;
 }
@@ -78,13 +87,31 @@ int oasr_encoder_create(const oasr_encoder_config* cfg, const oasr_top_weights* 
     return OASR_OK;
 }
 
+int oasr_encoder_set_fp8(oasr_encoder* enc, const oasr_layer_fp8_weights* layers) {
+    OASR_REQUIRE(enc, "encoder_set_fp8: null handle");
+    if (!layers) {
+        enc->fp8.clear();
+        return OASR_OK;
+    }
+    OASR_REQUIRE(enc->cfg.d_model % 64 == 0 && enc->cfg.ffn_dim % 64 == 0, "encoder_set_fp8: dimensions must be multiples of 64");
+    for (int l = 0; l < enc->cfg.n_layers; ++l) {
+        const oasr_layer_fp8_weights& w = layers[l];
+        OASR_REQUIRE(w.ffn1_w1_q && w.ffn1_w1_s && w.ffn1_w2_q && w.ffn1_w2_s && w.wqkv_q && w.wqkv_s && w.wo_q &&
+                         w.wo_s && w.pw1_q && w.pw1_s && w.pw2_q && w.pw2_s && w.ffn2_w1_q && w.ffn2_w1_s &&
+                         w.ffn2_w2_q && w.ffn2_w2_s,
+                     "encoder_set_fp8: layer %d has a null pointer", l);
+    }
+    enc->fp8.assign(layers, layers + enc->cfg.n_layers);
+    return OASR_OK;
+}
+
 void oasr_encoder_destroy(oasr_encoder* enc) { delete enc; }
 
 int64_t oasr_encoder_rows(int32_t batch, int64_t t_pad) { return round_up((int64_t)batch * t_pad, 256); }
 
 int64_t oasr_encoder_workspace_bytes(const oasr_encoder* enc, int32_t batch, int64_t t_pad) {
     if (!enc || batch <= 0 || t_pad <= 0) return 0;
-    return carve(enc->cfg, oasr_encoder_rows(batch, t_pad), nullptr).bytes;
+    return carve(enc->cfg, oasr_encoder_rows(batch, t_pad), nullptr, !enc->fp8.empty()).bytes;
 }
 
 int oasr_encoder_forward(const oasr_encoder* enc, const float* feats, const int32_t* lengths,
@@ -96,7 +123,8 @@ int oasr_encoder_forward(const oasr_encoder* enc, const float* feats, const int3
     const oasr_encoder_config& c = enc->cfg;
     const int64_t rows = oasr_encoder_rows(batch, t_pad);
     const int64_t live = (int64_t)batch * t_pad;
-    Workspace ws = carve(c, rows, reinterpret_cast<char*>(workspace));
+    const bool fp8 = !enc->fp8.empty();
+    Workspace ws = carve(c, rows, reinterpret_cast<char*>(workspace), fp8);
     if (ws.bytes > workspace_bytes) {
         set_error("encoder_forward: workspace needs %lld bytes, got %lld", (long long)ws.bytes,
                   (long long)workspace_bytes);
@@ -112,26 +140,35 @@ int oasr_encoder_forward(const oasr_encoder* enc, const float* feats, const int3
                             c.ln_eps, 1, 0, stream));
     OASR_TRY(oasr_gemm_bf16(ws.big, enc->top.fp_w, enc->top.fp_b, nullptr, x, rows, d, kFeatK, 1.0f,
                             OASR_EPI_BIAS_F32, stream));
+    // one large projection: bf16 GEMM, or row quantisation + fp8 GEMM when fp8 weights are set
+    auto project = [&](const uint16_t* a, int64_t k, const uint16_t* wb, const uint8_t* wq, const float* wscale,
+                       const float* bias, const float* resid, void* dst, int64_t n, float alpha, int epi) -> int {
+        if (!fp8) return oasr_gemm_bf16(a, wb, bias, resid, dst, rows, n, k, alpha, epi, stream);
+        OASR_TRY(oasr_quant_fp8_rows(a, rows, k, ws.a8, ws.sa, stream));
+        return oasr_gemm_fp8(ws.a8, wq, ws.sa, wscale, bias, resid, dst, rows, n, k, alpha, epi, stream);
+    };
+    static const oasr_layer_fp8_weights kNoFp8 = {};
     for (int l = 0; l < nl; ++l) {
         const oasr_layer_weights& w = enc->layers[l];
+        const oasr_layer_fp8_weights& q = fp8 ? enc->fp8[l] : kNoFp8;
         if (l == 0)
             OASR_TRY(oasr_layernorm(x, w.ffn1_ln_w, w.ffn1_ln_b, ws.xn, rows, d, d, c.ln_eps, 1, 0, stream));
         // half-step feed-forward 1
-        OASR_TRY(oasr_gemm_bf16(ws.xn, w.ffn1_w1, w.ffn1_b1, nullptr, ws.big, rows, f, d, 1.0f,
-                                OASR_EPI_BIAS_SWISH_BF16, stream));
-        OASR_TRY(oasr_gemm_bf16(ws.big, w.ffn1_w2, w.ffn1_b2, x, x, rows, d, f, 0.5f,
-                                OASR_EPI_RESIDUAL_F32, stream));
+        OASR_TRY(project(ws.xn, d, w.ffn1_w1, q.ffn1_w1_q, q.ffn1_w1_s, w.ffn1_b1, nullptr, ws.big, f, 1.0f,
+                         OASR_EPI_BIAS_SWISH_BF16));
+        OASR_TRY(project(ws.big, f, w.ffn1_w2, q.ffn1_w2_q, q.ffn1_w2_s, w.ffn1_b2, x, x, d, 0.5f,
+                         OASR_EPI_RESIDUAL_F32));
         // self-attention
         OASR_TRY(oasr_layernorm(x, w.attn_ln_w, w.attn_ln_b, ws.xn, rows, d, d, c.ln_eps, 1, 0, stream));
-        OASR_TRY(oasr_gemm_bf16(ws.xn, w.wqkv, w.bqkv, nullptr, ws.big, rows, 3 * (int64_t)d, d, 1.0f,
-                                OASR_EPI_BIAS_BF16, stream));
+        OASR_TRY(project(ws.xn, d, w.wqkv, q.wqkv_q, q.wqkv_s, w.bqkv, nullptr, ws.big, 3 * (int64_t)d, 1.0f,
+                         OASR_EPI_BIAS_BF16));
         OASR_TRY(oasr_attention_relkey(ws.big, w.dist_emb, lengths, ws.ctx, batch, t_pad, c.n_heads,
                                        c.left_max, c.right_max, stream));
-        OASR_TRY(oasr_gemm_bf16(ws.ctx, w.wo, w.bo, x, x, rows, d, d, 1.0f, OASR_EPI_RESIDUAL_F32, stream));
+        OASR_TRY(project(ws.ctx, d, w.wo, q.wo_q, q.wo_s, w.bo, x, x, d, 1.0f, OASR_EPI_RESIDUAL_F32));
         // convolution module
         OASR_TRY(oasr_layernorm(x, w.conv_ln_w, w.conv_ln_b, ws.xn, rows, d, d, c.ln_eps, 1, 0, stream));
-        OASR_TRY(oasr_gemm_bf16(ws.xn, w.pw1, nullptr, nullptr, ws.ctx, rows, 2 * (int64_t)d, d, 1.0f,
-                                OASR_EPI_GLU_BF16, stream));
+        OASR_TRY(project(ws.xn, d, w.pw1, q.pw1_q, q.pw1_s, nullptr, nullptr, ws.ctx, 2 * (int64_t)d, 1.0f,
+                         OASR_EPI_GLU_BF16));
         if (c.conv_kernel == 31 && (d == 512 || d == 1024 || d == 2048) && t_pad % 16 == 0) {
             OASR_TRY(oasr_dwconv_ln_swish(ws.ctx, w.dw, w.dw_ln_w, w.dw_ln_b, ws.xn, batch, t_pad, d,
                                           c.conv_kernel, c.ln_eps, stream));
@@ -139,13 +176,13 @@ int oasr_encoder_forward(const oasr_encoder* enc, const float* feats, const int3
             OASR_TRY(oasr_dwconv_causal(ws.ctx, w.dw, ws.tmp, batch, t_pad, d, c.conv_kernel, stream));
             OASR_TRY(oasr_layernorm(ws.tmp, w.dw_ln_w, w.dw_ln_b, ws.xn, live, d, d, c.ln_eps, 1, 1, stream));
         }
-        OASR_TRY(oasr_gemm_bf16(ws.xn, w.pw2, nullptr, x, x, rows, d, d, 1.0f, OASR_EPI_RESIDUAL_F32, stream));
+        OASR_TRY(project(ws.xn, d, w.pw2, q.pw2_q, q.pw2_s, nullptr, x, x, d, 1.0f, OASR_EPI_RESIDUAL_F32));
         // half-step feed-forward 2
         OASR_TRY(oasr_layernorm(x, w.ffn2_ln_w, w.ffn2_ln_b, ws.xn, rows, d, d, c.ln_eps, 1, 0, stream));
-        OASR_TRY(oasr_gemm_bf16(ws.xn, w.ffn2_w1, w.ffn2_b1, nullptr, ws.big, rows, f, d, 1.0f,
-                                OASR_EPI_BIAS_SWISH_BF16, stream));
-        OASR_TRY(oasr_gemm_bf16(ws.big, w.ffn2_w2, w.ffn2_b2, x, x, rows, d, f, 0.5f,
-                                OASR_EPI_RESIDUAL_F32, stream));
+        OASR_TRY(project(ws.xn, d, w.ffn2_w1, q.ffn2_w1_q, q.ffn2_w1_s, w.ffn2_b1, nullptr, ws.big, f, 1.0f,
+                         OASR_EPI_BIAS_SWISH_BF16));
+        OASR_TRY(project(ws.big, f, w.ffn2_w2, q.ffn2_w2_q, q.ffn2_w2_s, w.ffn2_b2, x, x, d, 0.5f,
+                         OASR_EPI_RESIDUAL_F32));
         // block output LayerNorm, fused with the next block's first LayerNorm when there is one
         if (l + 1 < nl) {
             const oasr_layer_weights& nx = enc->layers[l + 1];

@@ -41,6 +41,14 @@ class LayerWeights(C.Structure):
     _fields_ = [(n, c_vp) for n in LAYER_FIELDS]
 
 
+FP8_FIELDS = tuple(n + sfx for n in ("ffn1_w1", "ffn1_w2", "wqkv", "wo", "pw1", "pw2", "ffn2_w1", "ffn2_w2")
+                   for sfx in ("_q", "_s"))
+
+
+class LayerFp8Weights(C.Structure):
+    _fields_ = [(n, c_vp) for n in FP8_FIELDS]
+
+
 class TopWeights(C.Structure):
     _fields_ = [(n, c_vp) for n in TOP_FIELDS]
 
@@ -78,6 +86,9 @@ _SIGNATURES = {
     "oasr_layernorm": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_f32, c_i32, c_i32, c_vp]),
     "oasr_layernorm2": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_vp]),
     "oasr_gemm_bf16": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_i32, c_vp]),
+    "oasr_encoder_set_fp8": (c_i32, [c_vp, c_vp]),
+    "oasr_quant_fp8_rows": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    "oasr_gemm_fp8": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_i32, c_vp]),
     "oasr_attention_relkey": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp]),
     "oasr_dwconv_causal": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp]),
     "oasr_dwconv_ln_swish": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_f32, c_vp]),

@@ -26,7 +26,7 @@ def pad_frames(t: int) -> int:
 
 class HipEngine:
     def __init__(self, model="G300", *, weights: dict | None = None, seed: int = 0,
-                 device: int | str | torch.device | None = None, use_graphs: bool = True):
+                 device: int | str | torch.device | None = None, use_graphs: bool = True, fp8: bool = False):
         _hip.lib()
         _hip.require_device()
         self.geometry: Geometry = resolve_geometry(model)
@@ -37,7 +37,8 @@ class HipEngine:
         g = self.geometry
         if weights is None:
             weights = init_random_weights(g, seed)
-        self._packed = pack_for_device(weights, g, self.device)   # keeps device buffers alive
+        self.fp8 = bool(fp8)    # e4m3 weights + per-row quantised activations in the eight large projections
+        self._packed = pack_for_device(weights, g, self.device, fp8=self.fp8)   # keeps device buffers alive
         self._tables = torch.from_numpy(_hip.logmel_table_blob().view(np.int32)).to(self.device)
         self._handle = self._create_handle()
         self._buffers: dict = {}
@@ -58,6 +59,12 @@ class HipEngine:
         handle = C.c_void_p()
         _hip.check(_hip.lib().oasr_encoder_create(C.byref(cfg), C.byref(top), arr, C.byref(handle)),
                    "oasr_encoder_create")
+        if self.fp8:
+            q = (_hip.LayerFp8Weights * max(1, g.n_layers))()
+            for i, L in enumerate(self._packed["layers"]):
+                for k in _hip.FP8_FIELDS:
+                    setattr(q[i], k, L[k].data_ptr())
+            _hip.check(_hip.lib().oasr_encoder_set_fp8(handle, q), "oasr_encoder_set_fp8")
         return handle
 
     def close(self):

@@ -131,8 +131,19 @@ CTC_LOGIT_PITCH = 256   # columns of the logits matrix (one GEMM tile)
 ATTENTION_Q_SCALE = 1.4426950408889634
 
 
-def pack_for_device(weights: dict, g: Geometry, device) -> dict:
-    """Device tensors in the layout of `oasr_layer_weights` / `oasr_top_weights` (include/oasr.h)."""
+def quantize_rows_e4m3(w: torch.Tensor):
+    """Per-row OCP e4m3 quantisation: (codes uint8 [out, in], scale float32 [out]) with
+    w ~= codes * scale, scale = max|row| / 448 (1 for an all-zero row)."""
+    w = w.to(torch.float32)
+    amax = w.abs().amax(dim=1)
+    scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    codes = (w * (1.0 / scale)[:, None]).to(torch.float8_e4m3fn)
+    return codes.view(torch.uint8), scale
+
+
+def pack_for_device(weights: dict, g: Geometry, device, fp8: bool = False) -> dict:
+    """Device tensors in the layout of `oasr_layer_weights` / `oasr_top_weights` (include/oasr.h);
+    with `fp8`, also the e4m3 codes and row scales of `oasr_layer_fp8_weights`."""
     bf = lambda t: t.to(device=device, dtype=torch.bfloat16).contiguous()
     f32 = lambda t: t.to(device=device, dtype=torch.float32).contiguous()
     fp_w = torch.zeros((g.d_model, 192), dtype=torch.float32)
@@ -159,6 +170,13 @@ def pack_for_device(weights: dict, g: Geometry, device) -> dict:
             P[pfx + "_w2"], P[pfx + "_b2"] = bf(L[pfx + "_w2"]), f32(L[pfx + "_b2"])
         for n in ("ffn1_ln", "attn_ln", "conv_ln", "dw_ln", "ffn2_ln", "final_ln"):
             P[n + "_w"], P[n + "_b"] = f32(L[n + "_w"]), f32(L[n + "_b"])
+        if fp8:
+            mats = {"ffn1_w1": L["ffn1_w1"], "ffn1_w2": L["ffn1_w2"], "ffn2_w1": L["ffn2_w1"], "ffn2_w2": L["ffn2_w2"],
+                    "wqkv": torch.cat([L["wq"] * q_scale, L["wk"], L["wv"]], dim=0), "wo": L["wo"],
+                    "pw1": glu_interleave(L["pw1"]), "pw2": L["pw2"]}
+            for name, m in mats.items():
+                codes, scale = quantize_rows_e4m3(m)
+                P[name + "_q"], P[name + "_s"] = codes.to(device).contiguous(), f32(scale)
         layers.append(P)
     packed = {"top": top, "layers": layers}
     if "ctc_w" in weights:

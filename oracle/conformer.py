@@ -66,20 +66,38 @@ LAYER_KEYS = (
 )
 
 
+# When set, the eight large projections of a block emulate the device's fp8 mode: the input is
+# quantised per row and the weight per output row to OCP e4m3 (scale = max|row| / 448), the product
+# is taken on the de-quantised values.  Test infrastructure: set/reset by `forward(..., fp8=True)`.
+_FP8 = False
+
+
+def _fake_quant_rows(t):
+    amax = t.abs().amax(dim=-1, keepdim=True)
+    scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    return (t / scale).to(torch.float32).to(torch.float8_e4m3fn).to(t.dtype) * scale
+
+
+def _proj(x, w, b=None):
+    if _FP8:
+        return F.linear(_fake_quant_rows(x), _fake_quant_rows(w.to(x.dtype)), b)
+    return F.linear(x, w, b)
+
+
 def _swish(x):
     return x * torch.sigmoid(x)
 
 
 def _ffn(x, w, pfx):
-    return F.linear(_swish(F.linear(x, w[pfx + "_w1"], w[pfx + "_b1"])), w[pfx + "_w2"], w[pfx + "_b2"])
+    return _proj(_swish(_proj(x, w[pfx + "_w1"], w[pfx + "_b1"])), w[pfx + "_w2"], w[pfx + "_b2"])
 
 
 def attention(x, lengths, w, g: Geometry):
     b, t, d = x.shape
     h, dh = g.n_heads, g.head_dim
-    q = F.linear(x, w["wq"], w["bq"]).view(b, t, h, dh).transpose(1, 2)
-    k = F.linear(x, w["wk"], w["bk"]).view(b, t, h, dh).transpose(1, 2)
-    v = F.linear(x, w["wv"], w["bv"]).view(b, t, h, dh).transpose(1, 2)
+    q = _proj(x, w["wq"], w["bq"]).view(b, t, h, dh).transpose(1, 2)
+    k = _proj(x, w["wk"], w["bk"]).view(b, t, h, dh).transpose(1, 2)
+    v = _proj(x, w["wv"], w["bv"]).view(b, t, h, dh).transpose(1, 2)
     scale = 1.0 / math.sqrt(dh)
     scores = torch.matmul(q, k.transpose(-1, -2)) * scale
     pos = torch.arange(t)
@@ -91,18 +109,18 @@ def attention(x, lengths, w, g: Geometry):
     scores = scores.masked_fill(~key_ok[:, None, None, :], float("-inf"))
     p = torch.softmax(scores, dim=-1)
     ctx = torch.matmul(p, v).transpose(1, 2).reshape(b, t, d)
-    return F.linear(ctx, w["wo"], w["bo"])
+    return _proj(ctx, w["wo"], w["bo"])
 
 
 def conv_module(x, w, g: Geometry):
     d = g.d_model
     y = F.layer_norm(x, (d,), w["conv_ln_w"], w["conv_ln_b"], g.ln_eps)
-    y = F.linear(y, w["pw1"])
+    y = _proj(y, w["pw1"])
     y = y[..., :d] * torch.sigmoid(y[..., d:])               # GLU over the channel dim
     yt = F.pad(y.transpose(1, 2), (g.conv_kernel - 1, 0))
     yt = F.conv1d(yt, w["dw"][:, None, :], groups=d)
     y = F.layer_norm(yt.transpose(1, 2), (d,), w["dw_ln_w"], w["dw_ln_b"], g.ln_eps)
-    return F.linear(_swish(y), w["pw2"])
+    return _proj(_swish(y), w["pw2"])
 
 
 def block(x, lengths, w, g: Geometry, taps=None):
@@ -126,14 +144,19 @@ def input_projection(feats, w, g: Geometry):
 
 
 @torch.no_grad()
-def forward(feats, lengths, weights: dict, g: Geometry = G300, dtype=torch.float32, per_layer=False):
+def forward(feats, lengths, weights: dict, g: Geometry = G300, dtype=torch.float32, per_layer=False, fp8=False):
     """weights: {'fp_ln_w','fp_ln_b','fp_w','fp_b','layers': [ {LAYER_KEYS...} ]}.
     Returns hidden [B, T, d] (and the list of per-layer outputs when per_layer)."""
     cast = lambda t: t.to(dtype)
     top = {k: cast(v) for k, v in weights.items() if k != "layers"}
     x = input_projection(cast(feats), top, g)
     outs = [x]
-    for lw in weights["layers"]:
-        x = block(x, lengths, {k: cast(v) for k, v in lw.items()}, g)
-        outs.append(x)
+    global _FP8
+    _FP8 = bool(fp8)
+    try:
+        for lw in weights["layers"]:
+            x = block(x, lengths, {k: cast(v) for k, v in lw.items()}, g)
+            outs.append(x)
+    finally:
+        _FP8 = False
     return (x, outs) if per_layer else x

@@ -1,0 +1,144 @@
+"""GPU tests of the fp8 (e4m3) path through the C ABI: row quantisation and the fp8 GEMM against a
+float64 product of exactly the quantised operands (so the tolerance is accumulation order only)."""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+F8 = torch.float8_e4m3fn
+
+
+def _lib():
+    from omnilingual_asr import _hip
+    return _hip
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def quantize_rows_host(x: torch.Tensor):
+    """Per-row e4m3 quantisation as the kernel defines it (float32 arithmetic)."""
+    amax = x.abs().amax(dim=1)
+    scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    q = (x * (1.0 / scale)[:, None]).to(F8)
+    return q, scale
+
+
+def _quant_device(x_bf16: torch.Tensor):
+    H = _lib()
+    rows, k = x_bf16.shape
+    xd = x_bf16.cuda()
+    y = torch.zeros((rows, k), dtype=torch.uint8, device="cuda")
+    s = torch.zeros((rows,), dtype=torch.float32, device="cuda")
+    H.check(H.lib().oasr_quant_fp8_rows(xd.data_ptr(), rows, k, y.data_ptr(), s.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    return y, s
+
+
+@pytest.mark.parametrize("rows,k", [(7, 512), (256, 1024), (33, 4096), (5, 8)])
+def test_quant_fp8_rows(rows, k):
+    g = torch.Generator().manual_seed(rows + k)
+    x = (torch.randn((rows, k), generator=g) * torch.rand((rows, 1), generator=g) * 4).to(torch.bfloat16)
+    x[0] = 0                                                     # all-zero row: scale 1, zeros
+    y, s = _quant_device(x)
+    q_ref, s_ref = quantize_rows_host(x.float())
+    torch.testing.assert_close(s.cpu(), s_ref, rtol=2e-7, atol=0)
+    got = y.cpu().view(F8).float()
+    want = q_ref.float()
+    # identical up to division rounding: any mismatch is one e4m3 step on a value at a rounding boundary
+    bad = got != want
+    assert bad.float().mean() < 2e-3
+    assert ((got - want).abs()[bad] <= want.abs()[bad] / 8 + 2 ** -9).all()
+    assert (got[0] == 0).all() and s[0].item() == 1.0
+    assert got.abs().max() <= 448
+
+
+@pytest.mark.parametrize("m,n,k,epi", [
+    (256, 256, 64, 0), (512, 768, 1024, 0), (512, 512, 512, 1), (256, 512, 1024, 2), (512, 256, 2048, 3),
+    (256, 256, 192, 4), (4096, 1024, 1024, 3), (5120, 1024, 512, 1),
+])
+def test_gemm_fp8_epilogues(m, n, k, epi):
+    H = _lib()
+    g = torch.Generator().manual_seed(m + n + k + epi)
+    a = torch.randn((m, k), generator=g).to(torch.bfloat16)
+    w = torch.randn((n, k), generator=g) / math.sqrt(k)
+    bias = torch.randn((n,), generator=g)
+    a8, sa = _quant_device(a)
+    w8, sw = quantize_rows_host(w)
+    w8d, swd, bd = w8.view(torch.uint8).cuda(), sw.cuda(), bias.cuda()
+    a64 = a8.cpu().view(F8).double() * sa.cpu().double()[:, None]
+    w64 = w8.double() * sw.double()[:, None]
+    acc = a64 @ w64.t()
+    if epi in (3, 4):
+        c = torch.randn((m, n), generator=g).cuda()
+        c0 = c.cpu().double()
+    else:
+        c = torch.full((m, n // 2 if epi == 2 else n), float("nan"), dtype=torch.bfloat16, device="cuda")
+    H.check(H.lib().oasr_gemm_fp8(a8.data_ptr(), w8d.data_ptr(), sa.data_ptr(), swd.data_ptr(),
+                                  None if epi == 2 else bd.data_ptr(), c.data_ptr() if epi == 3 else None,
+                                  c.data_ptr(), m, n, k, 0.5, epi, _stream()))
+    torch.cuda.synchronize()
+    got = c.float().cpu().double()
+    if epi == 0:
+        ref, tol = acc + bias.double(), 1.2e-2
+    elif epi == 1:
+        z = acc + bias.double()
+        ref, tol = z * torch.sigmoid(z), 1.2e-2
+    elif epi == 2:   # interleaved rows: groups of 32 = 16 values then their 16 gates
+        t = acc.reshape(m, n // 32, 2, 16)
+        ref, tol = (t[:, :, 0] * torch.sigmoid(t[:, :, 1])).reshape(m, n // 2), 1.2e-2
+    elif epi == 3:
+        ref, tol = c0 + 0.5 * (acc + bias.double()), 2e-5
+    else:
+        ref, tol = acc + bias.double(), 2e-5
+    assert torch.isfinite(got).all()
+    # bf16 outputs: one rounding (2^-8 relative); float32 outputs: accumulation order only
+    torch.testing.assert_close(got, ref, atol=tol * float(ref.abs().max()), rtol=tol if tol > 1e-3 else 1e-5)
+
+
+def test_gemm_fp8_rejects_bad_shapes():
+    H = _lib()
+    z = torch.zeros((256, 256), dtype=torch.uint8, device="cuda")
+    s = torch.ones((256,), device="cuda")
+    c = torch.zeros((256, 256), dtype=torch.bfloat16, device="cuda")
+    call = lambda m, n, k, epi=0: H.lib().oasr_gemm_fp8(z.data_ptr(), z.data_ptr(), s.data_ptr(), s.data_ptr(), None, None,
+                                                        c.data_ptr(), m, n, k, 1.0, epi, _stream())
+    assert call(255, 256, 64) == -1 and call(256, 256, 96) == -1 and call(256, 256, 64, 9) == -1
+    assert call(256, 256, 64, 3) == -1 and b"resid" in H.lib().oasr_last_error()
+
+
+def test_encoder_fp8_matches_fake_quant_oracle():
+    """GTINY with fp8 projections against the oracle that quantises the same operands to e4m3: what
+    is left is bf16 activation rounding, as in the bf16 mode, so the same tolerance applies; the fp8
+    result must also differ from the bf16 one (the mode is really on)."""
+    from omnilingual_asr.engine_hip import HipEngine
+    from omnilingual_asr.weights import GEOMETRIES, init_random_weights
+    from oracle import conformer as OC
+    from oracle import logmel as OL
+    from tests.test_gpu_ops import synth_pcm
+
+    g = GEOMETRIES["GTINY"]
+    og = OC.Geometry(name=g.name, d_model=g.d_model, ffn_dim=g.ffn_dim, n_heads=g.n_heads, n_layers=g.n_layers)
+    w = init_random_weights(g, 21)
+    pcm = synth_pcm(2, 64000, seed=5)
+    n_valid = [64000, 41000]
+    feats, lens = OL.features_batch(pcm.numpy(), n_valid)
+    enc_w = {k: v for k, v in w.items() if not k.startswith("ctc_")}
+    ref8 = OC.forward(torch.from_numpy(feats), torch.from_numpy(lens), enc_w, og, fp8=True)
+    ref16 = OC.forward(torch.from_numpy(feats), torch.from_numpy(lens), enc_w, og)
+    eng8 = HipEngine("GTINY", weights=w, fp8=True)
+    h8, l8 = eng8.encode_batch(pcm, n_valid)
+    h8 = h8.cpu()
+    eng16 = HipEngine("GTINY", weights=w)
+    h16 = eng16.encode_batch(pcm, n_valid)[0].cpu()
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    for i, n in enumerate(lens):
+        assert int(l8[i]) == int(n)
+        assert rel(h8[i, :n], ref8[i, :n]) <= 3e-2            # vs the emulation of the same quantisation
+        assert rel(h8[i, :n], ref16[i, :n]) <= 1.5e-1           # stated fp8 tolerance vs the float32 oracle
+        assert rel(h8[i, :n], h16[i, :n]) > 5e-3               # and not the bf16 path
+    assert torch.isfinite(h8).all()
