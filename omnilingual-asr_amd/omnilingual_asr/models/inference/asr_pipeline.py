@@ -294,9 +294,13 @@ class GeminiASRPipeline:
             part = bounds[lo: lo + self.batch_size]
             width = int(max(e - s for s, e in part))
             width = max(width, 400)
-            batch = np.zeros((len(part), width), dtype=np.float32)
+            if hasattr(self.engine, "host_batch"):     # assemble directly in the engine's page-locked buffer
+                batch = self.engine.host_batch(len(part), width)
+            else:
+                batch = np.empty((len(part), width), dtype=np.float32)
             for i, (s, e) in enumerate(part):
                 batch[i, : e - s] = pcm[s:e]
+                batch[i, e - s:] = 0.0
             n_valid = [int(e - s) for s, e in part]
             try:
                 with self._engine_lock:
@@ -401,9 +405,13 @@ ASRPipeline = GeminiASRPipeline
 
 
 def _mean_abs(hidden, lengths) -> List[float]:
-    """Mean |state| over each utterance's valid frames (one small device reduction per batch)."""
-    out = []
-    for i, n in enumerate(lengths):
-        n = int(n)
-        out.append(float(hidden[i, :n].abs().mean()) if n > 0 else 0.0)
-    return out
+    """Mean |state| over each utterance's valid frames: one masked reduction and one copy per batch."""
+    import torch
+
+    h = hidden if isinstance(hidden, torch.Tensor) else torch.as_tensor(hidden)
+    n = torch.as_tensor(np.asarray(lengths, dtype=np.int64), device=h.device)
+    per_frame = h.abs().sum(dim=-1).to(torch.float64)                                     # [B, T]
+    mask = torch.arange(h.shape[1], device=h.device)[None, :] < n[:, None]
+    total = (per_frame * mask).sum(dim=1)
+    denom = (n * h.shape[2]).clamp(min=1).to(torch.float64)
+    return [float(v) for v in (total / denom).cpu()]

@@ -7,7 +7,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "omnilingual-asr_amd")); sys.path.insert(0, str(ROOT))
 import numpy as np, torch
 from omnilingual_asr.models.inference.asr_pipeline import GeminiASRPipeline, plan_chunks
-hours = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+hours = float(sys.argv[1]) if len(sys.argv) > 1 else 128 * 30 / 3600.0   # 128 chunks: whole batches only
 n = int(hours * 3600 * 16000)
 rng = np.random.default_rng(0)
 pcm = (0.1 * rng.standard_normal(n)).astype(np.float32)
