@@ -36,3 +36,15 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def tiny_engine():
+    """The CPU oracle behind the engine interface, at the smallest geometry (checker only)."""
+    from omnilingual_asr.weights import GEOMETRIES, init_random_weights
+    from oracle import conformer as OC
+    from oracle.engine import OracleEngine
+
+    g = GEOMETRIES["GTINY"]
+    og = OC.Geometry(name=g.name, d_model=g.d_model, ffn_dim=g.ffn_dim, n_heads=g.n_heads, n_layers=g.n_layers)
+    return OracleEngine(init_random_weights(g, 0), og)

@@ -26,17 +26,6 @@ def gold(golden_dir):
     return json.loads((golden_dir / "reference_host.json").read_text())
 
 
-@pytest.fixture(scope="module")
-def tiny_engine():
-    from omnilingual_asr.weights import GEOMETRIES, init_random_weights
-    from oracle import conformer as OC
-    from oracle.engine import OracleEngine
-
-    g = GEOMETRIES["GTINY"]
-    og = OC.Geometry(name=g.name, d_model=g.d_model, ffn_dim=g.ffn_dim, n_heads=g.n_heads, n_layers=g.n_layers)
-    return OracleEngine(init_random_weights(g, 0), og)
-
-
 def test_import_surface(gold):
     assert omnilingual_asr.__version__ == gold["reference_version"]
     assert GeminiDiarizedTranscriptionPipeline is Pipeline
