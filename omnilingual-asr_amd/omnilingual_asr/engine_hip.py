@@ -45,6 +45,8 @@ class HipEngine:
         self._graphs: dict = {}
         self._resample_tables: dict = {}
         self._pinned: dict = {}
+        self._tickets: dict = {}
+        self._copy_stream = None
         self.use_graphs = use_graphs
 
     # ---- set-up ---------------------------------------------------------------------------------------
@@ -284,3 +286,75 @@ class HipEngine:
             tok_h, frm_h, cnt_h = tok.cpu().numpy(), frm.cpu().numpy(), cnt.cpu().numpy()
             out = [(tok_h[i, : cnt_h[i]].copy(), frm_h[i, : cnt_h[i]].copy()) for i in range(tok_h.shape[0])]
             return hidden, lengths.cpu().numpy(), out
+
+    # ---- two-deep asynchronous path -------------------------------------------------------------------
+    # submit() queues one batch (upload on a copy stream, device path, CTC stage, masked activity, results
+    # to page-locked memory) and returns at once; collect() waits for that batch only.  With two slots
+    # the host assembles and uploads batch k+1 while the device works on batch k:
+    #     a = host_batch_slot(b, n, 0); fill a; ta = submit(a-slot) ...
+    # Intermediate device buffers are shared by both slots: batches run back to back on one stream.
+    def _ticket(self, b: int, n4: int, which: int):
+        key = (b, n4, which & 1)
+        t = self._tickets.get(key)
+        if t is None:
+            buf = self._get_buffers(b, n4)
+            t_pad = buf["t_pad"]
+            pin = lambda shape, dt: torch.zeros(shape, dtype=dt).pin_memory()
+            t = {
+                "key": key, "stage": pin((b, n4), torch.float32), "nv_pin": pin((b,), torch.int32),
+                "pcm_d": torch.zeros((b, n4), dtype=torch.float32, device=self.device),
+                "nv_d": torch.zeros((b,), dtype=torch.int32, device=self.device),
+                "tokens": pin((b, t_pad), torch.int32), "frames": pin((b, t_pad), torch.int32),
+                "counts": pin((b,), torch.int32), "lengths": pin((b,), torch.int32), "acts": pin((b,), torch.float64),
+                "copied": torch.cuda.Event(), "done": torch.cuda.Event(), "busy": False,
+            }
+            if len(self._tickets) >= 6:         # full batches and one tail shape, two slots each
+                self._tickets.pop(next(iter(self._tickets)))
+            self._tickets[key] = t
+        return t
+
+    def host_batch_slot(self, b: int, n: int, which: int):
+        """(ticket, page-locked [b, round_up(n, 4)] float32 array) of slot `which` (0 or 1).  Waits for
+        the slot's previous batch if it is still in flight, so the array is free to overwrite."""
+        with torch.cuda.device(self.device):
+            t = self._ticket(b, (n + 3) // 4 * 4, which)
+            if t["busy"]:
+                t["done"].synchronize()
+                t["busy"] = False
+            return t, t["stage"].numpy()
+
+    def submit(self, ticket, n_valid) -> None:
+        """Queue the batch assembled in the ticket's array; returns without waiting for the device."""
+        t = ticket
+        with torch.cuda.device(self.device):
+            if self._copy_stream is None:
+                self._copy_stream = torch.cuda.Stream(self.device)
+            main = torch.cuda.current_stream()
+            t["nv_pin"].numpy()[:] = np.asarray(n_valid, dtype=np.int32)
+            self._copy_stream.wait_event(t["done"])      # the slot's device copy may still feed its previous batch
+            with torch.cuda.stream(self._copy_stream):
+                t["pcm_d"].copy_(t["stage"], non_blocking=True)
+                t["nv_d"].copy_(t["nv_pin"], non_blocking=True)
+                t["copied"].record()
+            main.wait_event(t["copied"])
+            hidden, lengths = self._run(t["pcm_d"], t["nv_d"])
+            tok, frm, cnt = self.decode(hidden, lengths)
+            n = lengths.to(torch.int64)
+            per_frame = hidden.abs().sum(dim=-1).to(torch.float64)
+            mask = torch.arange(hidden.shape[1], device=self.device)[None, :] < n[:, None]
+            acts = (per_frame * mask).sum(dim=1) / (n * hidden.shape[2]).clamp(min=1).to(torch.float64)
+            for name, src in (("tokens", tok), ("frames", frm), ("counts", cnt), ("lengths", lengths), ("acts", acts)):
+                t[name].copy_(src, non_blocking=True)
+            t["done"].record()
+            t["busy"] = True
+
+    def collect(self, ticket):
+        """Wait for the ticket's batch: (lengths int32 [B], [(token ids, frame indices)] per row, mean
+        |state| per row).  The arrays are copies; the ticket can be reused at once."""
+        t = ticket
+        t["done"].synchronize()
+        t["busy"] = False
+        cnt = t["counts"].numpy()
+        tok, frm = t["tokens"].numpy(), t["frames"].numpy()
+        toks = [(tok[i, : cnt[i]].copy(), frm[i, : cnt[i]].copy()) for i in range(tok.shape[0])]
+        return t["lengths"].numpy().copy(), toks, [float(v) for v in t["acts"].numpy()]

@@ -10,6 +10,7 @@ over the ranks of a `torch.distributed` job (`omnilingual_asr.distributed`).
 
 from __future__ import annotations
 
+import contextlib
 import json
 import re
 import threading
@@ -287,35 +288,60 @@ class GeminiASRPipeline:
         return self._engine
 
     def _encode_chunks(self, pcm: np.ndarray, bounds: np.ndarray, first_idx: int = 0) -> List[ChunkRecord]:
-        """Run the chunks `bounds[i] = (start, end)` of `pcm` through the engine in batches."""
+        """Run the chunks `bounds[i] = (start, end)` of `pcm` through the engine in batches.  An engine
+        with `submit`/`collect` is driven two batches deep: batch k+1 is assembled in page-locked memory
+        and uploaded while the device works on batch k."""
         records: List[ChunkRecord] = []
         n = len(bounds)
-        for lo in range(0, n, self.batch_size):
-            part = bounds[lo: lo + self.batch_size]
-            width = int(max(e - s for s, e in part))
-            width = max(width, 400)
-            if hasattr(self.engine, "host_batch"):     # assemble directly in the engine's page-locked buffer
-                batch = self.engine.host_batch(len(part), width)
-            else:
-                batch = np.empty((len(part), width), dtype=np.float32)
-            for i, (s, e) in enumerate(part):
-                batch[i, : e - s] = pcm[s:e]
-                batch[i, e - s:] = 0.0
-            n_valid = [int(e - s) for s, e in part]
-            try:
-                with self._engine_lock:
-                    if hasattr(self.engine, "transcribe_batch"):
-                        hidden, lengths, toks = self.engine.transcribe_batch(batch, n_valid)
-                    else:
-                        hidden, lengths = self.engine.encode_batch(batch, n_valid)
-                        toks = [(None, None)] * len(part)
-                    acts = _mean_abs(hidden, lengths)
-            except Exception as exc:  # per-batch failure is tolerated, as per-chunk failure is in
-                print(f"Chunk transcription failed: {exc}")   # the reference (ref :635-641)
-                continue
+        pipelined = hasattr(self.engine, "submit")
+
+        def finish(lo, part, lengths, toks, acts):
             for i, (s, e) in enumerate(part):
                 records.append(ChunkRecord(first_idx + lo + i, int(s), int(e), int(lengths[i]), float(acts[i]),
                                            toks[i][0], toks[i][1]))
+
+        def collect(job):
+            lo, part, ticket = job
+            try:
+                finish(lo, part, *self.engine.collect(ticket))
+            except Exception as exc:  # per-batch failure is tolerated, as per-chunk failure is in
+                print(f"Chunk transcription failed: {exc}")   # the reference (ref :635-641)
+
+        in_flight = None
+        lock = self._engine_lock if pipelined else contextlib.nullcontext()
+        with lock:      # the two-deep path keeps the engine for the whole file
+            for k, lo in enumerate(range(0, n, self.batch_size)):
+                part = bounds[lo: lo + self.batch_size]
+                width = max(int(max(e - s for s, e in part)), 400)
+                n_valid = [int(e - s) for s, e in part]
+                try:
+                    if pipelined:
+                        ticket, batch = self.engine.host_batch_slot(len(part), width, k)
+                    else:
+                        ticket, batch = None, np.empty((len(part), width), dtype=np.float32)
+                    for i, (s, e) in enumerate(part):
+                        batch[i, : e - s] = pcm[s:e]
+                        batch[i, e - s:] = 0.0
+                    if pipelined:
+                        self.engine.submit(ticket, n_valid)
+                        job = (lo, part, ticket)
+                    else:
+                        with self._engine_lock:
+                            if hasattr(self.engine, "transcribe_batch"):
+                                hidden, lengths, toks = self.engine.transcribe_batch(batch, n_valid)
+                            else:
+                                hidden, lengths = self.engine.encode_batch(batch, n_valid)
+                                toks = [(None, None)] * len(part)
+                            finish(lo, part, lengths, toks, _mean_abs(hidden, lengths))
+                        job = None
+                except Exception as exc:
+                    print(f"Chunk transcription failed: {exc}")
+                    job = None
+                if in_flight is not None:
+                    collect(in_flight)
+                in_flight = job
+            if in_flight is not None:
+                collect(in_flight)
         return records
 
     def _load_audio(self, audio_path) -> np.ndarray:

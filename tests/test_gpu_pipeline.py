@@ -85,3 +85,33 @@ def test_full_size_batch_properties():
     junk[5, 250000:] = 1e3
     h2, _ = eng.step(junk, nv)
     torch.testing.assert_close(h2[5, : lens[5]], hidden[5, : lens[5]], atol=0, rtol=0)
+
+
+def test_two_deep_chunk_loop_equals_batch_at_a_time():
+    """The submit/collect loop (uploads overlapped with device work, two slots) returns exactly the
+    records of one synchronous `transcribe_batch` call per batch: 7 chunks of ragged length in batches of
+    2 (three full batches, then a tail batch of another shape)."""
+    from omnilingual_asr.models.inference.asr_pipeline import GeminiASRPipeline, _mean_abs
+
+    rng = np.random.default_rng(3)
+    pcm = (0.1 * rng.standard_normal(16000 * 40)).astype(np.float32)
+    cuts = [0, 96000, 192000, 250000, 346000, 442000, 538000, 600000]
+    bounds = np.array(list(zip(cuts[:-1], cuts[1:])), dtype=np.int64)
+    pipe = GeminiASRPipeline(model="GTINY", seed=2, batch_size=2)
+    for _ in range(2):                      # second pass: slots and graphs are reused
+        recs = pipe._encode_chunks(pcm, bounds, first_idx=10)
+        assert [r.chunk_idx for r in recs] == list(range(10, 17))
+        for lo in range(0, 7, 2):
+            part = bounds[lo: lo + 2]
+            width = int(max(e - s for s, e in part))
+            batch = np.zeros((len(part), width), dtype=np.float32)
+            for i, (s, e) in enumerate(part):
+                batch[i, : e - s] = pcm[s:e]
+            hidden, lengths, toks = pipe.engine.transcribe_batch(batch, [int(e - s) for s, e in part])
+            acts = _mean_abs(hidden, lengths)
+            for i in range(len(part)):
+                r = recs[lo + i]
+                assert (r.start_sample, r.end_sample, r.n_frames) == (part[i][0], part[i][1], int(lengths[i]))
+                assert r.activity == acts[i]
+                np.testing.assert_array_equal(r.tokens, toks[i][0])
+                np.testing.assert_array_equal(r.frames, toks[i][1])

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B timing of several builds of the GEMM entry point in one process (tuning aid).
-Usage: gemm_cmp.py lib1.so lib2.so ...   Builds are interleaved launch by launch so that clock and
+Usage: gemm_cmp.py [--blas] lib1.so lib2.so ...   (--blas adds a column for the library GEMM behind
+torch.matmul on the same operands: bf16 output, no bias, no activation, no residual).  Builds are interleaved launch by launch so that clock and
 temperature drift hits them equally; each timed launch follows a kernel that rewrites the A operand
 (as the LayerNorm does in the encoder), with HIP events around the GEMM only."""
 import ctypes as C
@@ -10,13 +11,16 @@ import torch
 
 libs = []
 vp = C.c_void_p
-for path in sys.argv[1:]:
+with_blas = "--blas" in sys.argv
+for path in [a for a in sys.argv[1:] if a != "--blas"]:
     L = C.CDLL(str(Path(path).resolve()))
     L.oasr_gemm_bf16.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_int32, vp]
     libs.append((Path(path).stem, L))
 cases = [("ffn_up swish", 48128, 4096, 1024, 1), ("ffn_down resid", 48128, 1024, 4096, 3),
          ("qkv bias", 48128, 3072, 1024, 0), ("out resid", 48128, 1024, 1024, 3),
          ("glu", 48128, 2048, 1024, 2), ("b1 ffn_up", 1536, 4096, 1024, 1)]
+if with_blas:
+    libs.append(("torch.matmul", None))
 dev = torch.device("cuda")
 st = torch.cuda.current_stream().cuda_stream
 iters = 12
@@ -32,13 +36,14 @@ for name, m, n, k, epi in cases:
         torch.zeros((m, n // 2 if epi == 2 else n), dtype=torch.bfloat16, device=dev)
     args = (a.data_ptr(), w.data_ptr(), None if epi == 2 else bias.data_ptr(), c.data_ptr() if epi == 3 else None,
             c.data_ptr(), m, n, k, 1.0, epi, st)
+    out_blas = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
     times = [[] for _ in libs]
     for it in range(iters + 2):
         for li, (_, L) in enumerate(libs):
             a.copy_(a_src)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            rc = L.oasr_gemm_bf16(*args)
+            rc = L.oasr_gemm_bf16(*args) if L is not None else (torch.matmul(a, w.t(), out=out_blas), 0)[1]
             e1.record()
             assert rc == 0
             e1.synchronize()
