@@ -267,7 +267,8 @@ class GeminiASRPipeline:
     def __init__(self, api_key: Optional[str] = None, model: str = "gemini-3-flash-preview", *,
                  engine: Any = None, device: Any = None, chunk_seconds: float = DEFAULT_CHUNK_SECONDS,
                  min_chunking_seconds: float = DEFAULT_MIN_CHUNKING_SECONDS,
-                 batch_size: int = DEFAULT_BATCH, seed: int = 0, process_group: Any = None) -> None:
+                 batch_size: int = DEFAULT_BATCH, seed: int = 0, process_group: Any = None,
+                 fp8: bool = False) -> None:
         self.api_key = api_key
         self.model = model
         self.chunk_seconds = float(chunk_seconds)
@@ -276,6 +277,7 @@ class GeminiASRPipeline:
         self.process_group = process_group
         self._device = device
         self._seed = seed
+        self._fp8 = bool(fp8)
         self._engine = engine
         self._engine_lock = threading.Lock()   # one device stream: concurrent callers serialise here
 
@@ -284,7 +286,7 @@ class GeminiASRPipeline:
     def engine(self):
         if self._engine is None:
             from omnilingual_asr.engine_hip import HipEngine
-            self._engine = HipEngine(self.model, seed=self._seed, device=self._device)
+            self._engine = HipEngine(self.model, seed=self._seed, device=self._device, fp8=self._fp8)
         return self._engine
 
     def _encode_chunks(self, pcm: np.ndarray, bounds: np.ndarray, first_idx: int = 0) -> List[ChunkRecord]:
