@@ -29,6 +29,7 @@ import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+MFMA_FP8_PEAK_TFLOPS = 5000.0   # dense fp8
 
 
 def synth_batch(batch: int, n: int, seed: int) -> torch.Tensor:
@@ -323,7 +324,8 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": "fp8 (e4m3) projections, bf16 elsewhere" if args.fp8 else "bf16",
             "data": "synthetic (seeded noise + 440 Hz tone), random-init weights seed 0",
-            "config": {"workload": ("BASELINE configs[2]" if g.name == "G300" else "geometry of BASELINE configs[4]") + (" fp8" if args.fp8 else "") +
+            "config": {"workload": ("BASELINE configs[2]" if g.name == "G300" else "BASELINE configs[4]" if args.fp8 else
+                                    "geometry of BASELINE configs[4] in bf16") + (" fp8" if args.fp8 and g.name == "G300" else "") +
                                    ": batch=%d x %.0f s chunks @16 kHz, log-mel + %s encoder "
                                    "(%d blocks, d=%d, %.0fM params), %s" %
                                    (args.batch, args.seconds, g.name, g.n_layers, g.d_model, g.n_params() / 1e6,
@@ -331,7 +333,9 @@ def main() -> None:
                        "global_batch": world * args.batch, "frames_per_utterance": int(t_frames),
                        "parallelism": "chunks sharded over %d rank(s), one all-gather of records" % world},
             "encoder_tflops": round(flops_step / (elapsed / args.steps) / 1e12, 1),
-            "encoder_mfma_frac": round(flops_step / (elapsed / args.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "encoder_mfma_frac": round(flops_step / (elapsed / args.steps) / 1e12 /
+                                       (MFMA_FP8_PEAK_TFLOPS if args.fp8 else MFMA_BF16_PEAK_TFLOPS), 4),
+            "encoder_mfma_peak": MFMA_FP8_PEAK_TFLOPS if args.fp8 else MFMA_BF16_PEAK_TFLOPS,
         }
         if not args.no_kernel_timing:
             line.update(kernel_rooflines(engine, args.batch, pad_frames(t_frames), pcm, nv, hidden))

@@ -1,10 +1,13 @@
 // Fused multi-head self-attention for gfx950 with clamped relative-key bias and key-length mask:
-//   scores[i][j] = (q_i . k_j + q_i . E[clip(j - i, -L, R) + L]) / sqrt(64);  softmax over j < len;
-//   ctx_i = sum_j p[i][j] v_j.
-// The caller hands in q already multiplied by log2(e) / sqrt(64) (folded into the q rows of the
+//   scores[i][j] = (q_i . k_j + q_i . E[clip(j - i, -L, R) + L]) / sqrt(head);  softmax over j < len;
+//   ctx_i = sum_j p[i][j] v_j,  head size 64 or 128.
+// The caller hands in q already multiplied by log2(e) / sqrt(head) (folded into the q rows of the
 // fused projection), so the MFMA results are scores in log2 units and no per-element scaling is left.
-// Flash-style: the T x T scores never leave the CU.  A 256-thread work-group owns 128 query rows
-// of one (utterance, head); each wavefront owns 32 of them and walks the keys in tiles of 64.
+// Flash-style: the T x T scores never leave the CU.  Each wavefront owns 32 query rows of one
+// (utterance, head) and walks the keys in tiles of 64.  Head size 64: 4 waves (128 queries) per
+// work-group, three work-groups per CU.  Head size 128: K and V tiles are twice as large and a wave
+// needs twice the output accumulators, so 8 waves (256 queries) share one pair of tiles and one
+// work-group fills a CU (two waves per SIMD, as before).
 //
 // MFMA orientation (v_mfma_f32_32x32x16_bf16): S^T = K . Q^T, so a lane holds one query column and
 // 16 keys of it in registers — the row max is in-register plus one exchange with lane^32, and the
@@ -24,9 +27,7 @@
 
 namespace oasr {
 
-constexpr int kQBlock = 128;   // query rows per work-group (32 per wave)
 constexpr int kKTile = 64;     // keys per iteration
-constexpr int kHead = 64;      // head size
 constexpr int kDistRows = 96;  // rows of the (zero padded) distance-embedding table in global memory
 constexpr int kQeRows = 80;    // rows of q.E kept in LDS (>= left_max + right_max + 1)
 constexpr float kRescaleThreshold = 6.0f;  // log2 units: the running max is raised only past this
@@ -55,25 +56,42 @@ __device__ __forceinline__ float max32(const f32x16& a, const f32x16& b) {
 }
 
 // LDS images, double buffered (one barrier per key tile):
-//   k : [key][64 d] bf16, 128-byte rows; 16-byte chunk c of key r sits at chunk c ^ ((r >> 1) & 7),
-//       which makes the 32-row ds_read_b128 fragment reads conflict-free
-//   v : [key][64 d] bf16 as it lies in memory, 128-byte rows; chunk c of key r sits at chunk
-//       c ^ (((r >> 1) & 1) << 2).  The V^T operand of O^T = V^T . P^T is fetched with the transposing
-//       read ds_read_b64_tr_b16 (per 16 lanes a block of 4 keys x 16 channels, delivered as 4 keys
-//       of one channel per lane); with that swizzle the four keys of a block fall into four
-//       different bank quarters, so the reads and the 16-byte staging writes are conflict-free
+//   k : [key][HD] bf16, rows of 2 HD bytes; 16-byte chunk c of key r sits at chunk c ^ kswz(r), which
+//       makes the 32-row ds_read_b128 fragment reads conflict-free: kswz(r) = (r >> 1) & 7 for 128-byte
+//       rows (two rows span the 64 banks), r & 15 for 256-byte rows (the 16 lanes of a read group
+//       hold 16 different values of r & 15)
+//   v : [key][HD] bf16 as it lies in memory; chunk c of key r sits at chunk c ^ vswz(r).  The V^T
+//       operand of O^T = V^T . P^T is fetched with the transposing read ds_read_b64_tr_b16 (per 16
+//       lanes a block of 4 keys x 16 channels, delivered as 4 keys of one channel per lane); vswz
+//       sends the four keys of a block to four different bank quarters (((r >> 1) & 1) << 2 for
+//       128-byte rows, where odd rows already start half a bank period later; (r & 3) << 2 for
+//       256-byte rows), so the reads and the 16-byte staging writes are conflict-free
+template <int HD>
 struct AttnSmem {
-    __attribute__((aligned(16))) char k[2][kKTile * 128];
-    __attribute__((aligned(16))) char v[2][kKTile * 128];
-    __attribute__((aligned(16))) _Float16 qe[4][kQeRows * 32];   // per wave: [c][q] = q . E[c] (fp16: three work-groups fit one CU)
+    static constexpr int kWaves = HD / 16;   // 4 or 8
+    __attribute__((aligned(16))) char k[2][kKTile * HD * 2];
+    __attribute__((aligned(16))) char v[2][kKTile * HD * 2];
+    __attribute__((aligned(16))) _Float16 qe[kWaves][kQeRows * 32];   // per wave: [c][q] = q . E[c] (fp16 keeps the work-group small)
 };
 
-__global__ __launch_bounds__(256, 3) void attention_relkey_kernel(
+template <int HD>
+__device__ __forceinline__ int kswz(int r) { return HD == 64 ? (r >> 1) & 7 : r & 15; }
+template <int HD>
+__device__ __forceinline__ int vswz(int r) { return HD == 64 ? ((r >> 1) & 1) << 2 : (r & 3) << 2; }
+
+template <int HD>
+__global__ __launch_bounds__(HD * 4, HD == 64 ? 3 : 1) void attention_relkey_kernel(
     const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dist_emb,
     const int32_t* __restrict__ lengths, uint16_t* __restrict__ ctx, int t_pad, int n_heads,
     int q_blocks, int left_max, int right_max) {
+    constexpr int kHead = HD;
+    constexpr int kRowB = HD * 2;          // bytes per K / V row in LDS
+    constexpr int kSteps = HD / 16;        // MFMA k-steps of S^T = K . Q^T
+    constexpr int kOut = HD / 32;          // 32-channel output accumulators per wave
+    constexpr int kCpr = HD / 8;           // 16-byte chunks per row
+    constexpr int kQBlock = 32 * (HD / 16);  // query rows per work-group
     const int d_model = n_heads * kHead;
-    __shared__ AttnSmem sm;
+    __shared__ AttnSmem<HD> sm;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
@@ -97,12 +115,12 @@ __global__ __launch_bounds__(256, 3) void attention_relkey_kernel(
     const int n_dist = left_max + right_max + 1;
 
     // ---- Q fragments (B operand): lane (r, hh) holds Q[qw0 + r][16 s + 8 hh .. +8], s = 0..3 ---------
-    bf16x8 qf[4];
+    bf16x8 qf[kSteps];
     {
         const int qrow = min(qw0 + r, t_pad - 1);
         const uint16_t* qp = base + qrow * ld + 8 * hh;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+        for (int s = 0; s < kSteps; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
     }
     // ---- QE^T[c][q] = E[c] . Q[q]: 32-row blocks of the distance table ---------------------------------
     _Float16* qe = sm.qe[wave];
@@ -114,7 +132,7 @@ __global__ __launch_bounds__(256, 3) void attention_relkey_kernel(
             for (int e = 0; e < 16; ++e) acc[e] = 0.f;
             const uint16_t* ep = dist_emb + (cb * 32 + r) * kHead + 8 * hh;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < kSteps; ++s) {
                 const bf16x8 ef = *reinterpret_cast<const bf16x8*>(ep + 16 * s);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ef, qf[s], acc, 0, 0, 0);
             }
@@ -132,11 +150,11 @@ __global__ __launch_bounds__(256, 3) void attention_relkey_kernel(
     const float bias_left = wave_active ? (float)qe[0 * 32 + r] : 0.f;
     const float bias_right = wave_active ? (float)qe[(n_dist - 1) * 32 + r] : 0.f;
 
-    f32x16 o0, o1, lacc, offv;
+    f32x16 o[kOut], lacc, offv;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-        o0[e] = 0.f;
-        o1[e] = 0.f;
+#pragma unroll
+        for (int db = 0; db < kOut; ++db) o[db][e] = 0.f;
         lacc[e] = 0.f;
         offv[e] = 0.f;
     }
@@ -147,14 +165,15 @@ __global__ __launch_bounds__(256, 3) void attention_relkey_kernel(
     for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;   // bf16 1.0
 
     // ---- staging roles ------------------------------------------------------------------------------------
-    // K and V: thread copies 16-byte chunks (key = tid >> 3 (+32), chunk = tid & 7)
-    const int srow = tid >> 3, schunk = tid & 7;
+    // K and V: thread copies 16-byte chunks (key = tid / chunks-per-row (+32), chunk = tid % chunks-per-row)
+    const int srow = tid / kCpr, schunk = tid % kCpr;   // 32 rows per pass in both configurations
     const int n_tiles = (len + kKTile - 1) / kKTile;
     const int last_row = t_pad - 1;
-    const int k_lds0 = srow * 128 + ((schunk ^ ((srow >> 1) & 7)) << 4);
-    const int k_lds1 = (32 + srow) * 128 + ((schunk ^ (((32 + srow) >> 1) & 7)) << 4);
-    const int v_lds0 = srow * 128 + ((schunk ^ (((srow >> 1) & 1) << 2)) << 4);
-    const int v_lds1 = v_lds0 + 32 * 128;   // (32 + srow) >> 1 has the same low bit
+    // adding 32 to a key changes none of the bits the swizzles look at
+    const int k_lds0 = srow * kRowB + ((schunk ^ kswz<HD>(srow)) << 4);
+    const int k_lds1 = k_lds0 + 32 * kRowB;
+    const int v_lds0 = srow * kRowB + ((schunk ^ vswz<HD>(srow)) << 4);
+    const int v_lds1 = v_lds0 + 32 * kRowB;
 
     // named registers (not arrays: an array captured by the lambdas below ends up in scratch memory,
     // which forces a wait right after each global load and defeats the prefetch)
@@ -199,21 +218,21 @@ __global__ __launch_bounds__(256, 3) void attention_relkey_kernel(
     };
 
     // K fragment addresses: lane (r, hh) reads key r (+32), logical chunk 2 s + hh
-    int k_frag[4];
+    int k_frag[kSteps];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) k_frag[s] = r * 128 + (((2 * s + hh) ^ ((r >> 1) & 7)) << 4);
-    // (32 + r) >> 1 = 16 + (r >> 1): same low three bits, so the second half only adds 32 rows
+    for (int s = 0; s < kSteps; ++s) k_frag[s] = r * kRowB + (((2 * s + hh) ^ kswz<HD>(r)) << 4);
+    // kswz(32 + r) = kswz(r), so the second half only adds 32 rows
     // V^T fragments by transposing reads.  In its group of 16 lanes, lane 4 q + p supplies the address
     // of key (block base + q), channels 16 (g & 1) + 4 p .. + 3, and receives the block's 4 keys of
     // channel 16 (g & 1) + (lane & 15) = lane & 31 (g = lane >> 4; hh = g >> 1 picks the keys).
     // Block base of piece w of k-step (u, s2): key 32 u + 16 s2 + 8 w + 4 hh.
     const int tq = (lane >> 2) & 3, tp = lane & 3, tg = (lane >> 4) & 1;
-    int v_frag[2];   // byte offset inside the tile for db = 0, 1 at key block 0 (key = 4 hh + tq)
+    int v_frag[kOut];   // byte offset inside the tile for output block db at key block 0 (key = 4 hh + tq)
 #pragma unroll
-    for (int db = 0; db < 2; ++db) {
+    for (int db = 0; db < kOut; ++db) {
         const int key = 4 * hh + tq;
         const int cbyte = (32 * db + 16 * tg + 4 * tp) * 2;   // byte offset of the channels inside the row
-        v_frag[db] = key * 128 + ((((cbyte >> 4) ^ (((key >> 1) & 1) << 2)) << 4) | (cbyte & 15));
+        v_frag[db] = key * kRowB + ((((cbyte >> 4) ^ vswz<HD>(key)) << 4) | (cbyte & 15));
     }
 
     load_tile(0);
@@ -252,9 +271,9 @@ __global__ __launch_bounds__(256, 3) void attention_relkey_kernel(
                 }
             }
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < kSteps; ++s) {
                 const bf16x8 ka = *reinterpret_cast<const bf16x8*>(kbuf + k_frag[s]);
-                const bf16x8 kb = *reinterpret_cast<const bf16x8*>(kbuf + 32 * 128 + k_frag[s]);
+                const bf16x8 kb = *reinterpret_cast<const bf16x8*>(kbuf + 32 * kRowB + k_frag[s]);
                 s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], s0, 0, 0, 0);
                 s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb, qf[s], s1, 0, 0, 0);
             }
@@ -292,8 +311,8 @@ __global__ __launch_bounds__(256, 3) void attention_relkey_kernel(
                 m_run += delta;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    o0[e] *= alpha;
-                    o1[e] *= alpha;
+#pragma unroll
+                    for (int db = 0; db < kOut; ++db) o[db][e] *= alpha;
                     lacc[e] *= alpha;
                     s0[e] -= delta;
                     s1[e] -= delta;
@@ -320,19 +339,16 @@ __global__ __launch_bounds__(256, 3) void attention_relkey_kernel(
 #pragma unroll
                     for (int j = 0; j < 4; ++j) pw[j] = cvt_pk_bf16(sv[8 * s2 + 2 * j], sv[8 * s2 + 2 * j + 1]);
                     const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
-                    // key blocks 32 u + 16 s2 + 8 w (+ 4 hh + tq in v_frag): multiples of 8 keep ((key >> 1) & 1)
-                    const int kb_off = (32 * u + 16 * s2) * 128;
+                    // key blocks 32 u + 16 s2 + 8 w (+ 4 hh + tq in v_frag): multiples of 8 leave vswz alone
+                    const int kb_off = (32 * u + 16 * s2) * kRowB;
 #pragma unroll
-                    for (int db = 0; db < 2; ++db) {
+                    for (int db = 0; db < kOut; ++db) {
                         typedef __attribute__((ext_vector_type(4))) short s16x4;
                         typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
                         const s16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vbuf + kb_off + v_frag[db]));
-                        const s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vbuf + kb_off + 8 * 128 + v_frag[db]));
+                        const s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vbuf + kb_off + 8 * kRowB + v_frag[db]));
                         const bf16x8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
-                        if (db == 0)
-                            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o0, 0, 0, 0);
-                        else
-                            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o1, 0, 0, 0);
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
                     }
                     lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);
                 }
@@ -371,13 +387,13 @@ __global__ __launch_bounds__(256, 3) void attention_relkey_kernel(
     if (q < t_pad) {
         uint16_t* op = ctx + ((int64_t)b * t_pad + q) * d_model + head * kHead + 4 * hh;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            uint2 pk0 = make_uint2(cvt_pk_bf16(o0[4 * g] * inv, o0[4 * g + 1] * inv),
-                                   cvt_pk_bf16(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
-            uint2 pk1 = make_uint2(cvt_pk_bf16(o1[4 * g] * inv, o1[4 * g + 1] * inv),
-                                   cvt_pk_bf16(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
-            *reinterpret_cast<uint2*>(op + 8 * g) = pk0;
-            *reinterpret_cast<uint2*>(op + 32 + 8 * g) = pk1;
+        for (int db = 0; db < kOut; ++db) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint2 pk = make_uint2(cvt_pk_bf16(o[db][4 * g] * inv, o[db][4 * g + 1] * inv),
+                                            cvt_pk_bf16(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv));
+                *reinterpret_cast<uint2*>(op + 32 * db + 8 * g) = pk;
+            }
         }
     }
 }
@@ -388,20 +404,26 @@ using namespace oasr;
 
 extern "C" int oasr_attention_relkey(const uint16_t* qkv, const uint16_t* dist_emb,
                                      const int32_t* lengths, uint16_t* ctx, int32_t batch,
-                                     int64_t t_pad, int32_t n_heads, int32_t left_max,
+                                     int64_t t_pad, int32_t n_heads, int32_t head_dim, int32_t left_max,
                                      int32_t right_max, void* stream) {
     OASR_REQUIRE(qkv && dist_emb && lengths && ctx, "attention: null pointer");
     OASR_REQUIRE(batch > 0 && batch <= 65535 && n_heads > 0 && n_heads <= 65535, "attention: bad batch/heads");
+    OASR_REQUIRE(head_dim == 64 || head_dim == 128, "attention: head size %d (64 and 128 are built)", head_dim);
     OASR_REQUIRE(t_pad > 0 && t_pad % 32 == 0, "attention: t_pad must be a positive multiple of 32");
     OASR_REQUIRE(left_max >= 0 && right_max >= 0 && left_max + right_max + 1 <= kQeRows,
                  "attention: left_max + right_max + 1 must be <= %d", kQeRows);
-    OASR_REQUIRE((int64_t)batch * t_pad * 3 * n_heads * kHead < ((int64_t)1 << 31),
+    OASR_REQUIRE((int64_t)batch * t_pad * 3 * n_heads * head_dim < ((int64_t)1 << 31),
                  "attention: qkv matrix too large for 32-bit element offsets");
-    const int q_blocks = (int)((t_pad + kQBlock - 1) / kQBlock);
+    const int q_block = 2 * head_dim;   // 32 query rows per wave, head_dim / 16 waves
+    const int q_blocks = (int)((t_pad + q_block - 1) / q_block);
     OASR_REQUIRE((int64_t)q_blocks * n_heads * batch < ((int64_t)1 << 31), "attention: too many work items");
     dim3 grid((unsigned)(q_blocks * n_heads * batch));
-    hipLaunchKernelGGL(attention_relkey_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv,
-                       dist_emb, lengths, ctx, (int)t_pad, n_heads, q_blocks, left_max, right_max);
+    if (head_dim == 64)
+        hipLaunchKernelGGL(attention_relkey_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, qkv,
+                           dist_emb, lengths, ctx, (int)t_pad, n_heads, q_blocks, left_max, right_max);
+    else
+        hipLaunchKernelGGL(attention_relkey_kernel<128>, grid, dim3(512), 0, (hipStream_t)stream, qkv,
+                           dist_emb, lengths, ctx, (int)t_pad, n_heads, q_blocks, left_max, right_max);
     OASR_CHECK_LAUNCH("attention");
     return OASR_OK;
 }

@@ -70,7 +70,8 @@ int oasr_encoder_create(const oasr_encoder_config* cfg, const oasr_top_weights* 
     OASR_REQUIRE(cfg->d_model > 0 && cfg->d_model % 512 == 0 && cfg->d_model <= 4096,
                  "encoder_create: d_model must be a multiple of 512, at most 4096");
     OASR_REQUIRE(cfg->ffn_dim > 0 && cfg->ffn_dim % 256 == 0, "encoder_create: ffn_dim must be a multiple of 256");
-    OASR_REQUIRE(cfg->n_heads > 0 && cfg->d_model == cfg->n_heads * 64, "encoder_create: head size must be 64");
+    OASR_REQUIRE(cfg->n_heads > 0 && (cfg->d_model == cfg->n_heads * 64 || cfg->d_model == cfg->n_heads * 128),
+                 "encoder_create: head size (d_model / n_heads) must be 64 or 128");
     OASR_REQUIRE(cfg->conv_kernel == 31 || cfg->conv_kernel == 15 || cfg->conv_kernel == 7 || cfg->conv_kernel == 3,
                  "encoder_create: conv_kernel must be 3, 7, 15 or 31");
     OASR_REQUIRE(cfg->left_max >= 0 && cfg->right_max >= 0 && cfg->left_max + cfg->right_max + 1 <= 96,
@@ -163,7 +164,7 @@ int oasr_encoder_forward(const oasr_encoder* enc, const float* feats, const int3
         OASR_TRY(project(ws.xn, d, w.wqkv, q.wqkv_q, q.wqkv_s, w.bqkv, nullptr, ws.big, 3 * (int64_t)d, 1.0f,
                          OASR_EPI_BIAS_BF16));
         OASR_TRY(oasr_attention_relkey(ws.big, w.dist_emb, lengths, ws.ctx, batch, t_pad, c.n_heads,
-                                       c.left_max, c.right_max, stream));
+                                       c.d_model / c.n_heads, c.left_max, c.right_max, stream));
         OASR_TRY(project(ws.ctx, d, w.wo, q.wo_q, q.wo_s, w.bo, x, x, d, 1.0f, OASR_EPI_RESIDUAL_F32));
         // convolution module
         OASR_TRY(oasr_layernorm(x, w.conv_ln_w, w.conv_ln_b, ws.xn, rows, d, d, c.ln_eps, 1, 0, stream));

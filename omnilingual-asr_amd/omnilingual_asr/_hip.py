@@ -89,7 +89,7 @@ _SIGNATURES = {
     "oasr_encoder_set_fp8": (c_i32, [c_vp, c_vp]),
     "oasr_quant_fp8_rows": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "oasr_gemm_fp8": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_i32, c_vp]),
-    "oasr_attention_relkey": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp]),
+    "oasr_attention_relkey": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "oasr_dwconv_causal": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp]),
     "oasr_dwconv_ln_swish": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_f32, c_vp]),
     "oasr_resample_length": (c_i64, [c_i64, c_i32, c_i32]),

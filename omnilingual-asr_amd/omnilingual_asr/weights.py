@@ -48,7 +48,7 @@ class Geometry:
 
 GEOMETRIES = {
     "G300": Geometry(),
-    "G7B": Geometry(name="G7B", d_model=4096, ffn_dim=16384, n_heads=64, n_layers=18),
+    "G7B": Geometry(name="G7B", d_model=4096, ffn_dim=16384, n_heads=32, n_layers=18),
     # small shapes for tests
     "GTINY": Geometry(name="GTINY", d_model=512, ffn_dim=1024, n_heads=8, n_layers=2),
 }

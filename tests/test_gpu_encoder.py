@@ -24,7 +24,7 @@ def _run_case(geom_name, n_list, n_layers_cut=None, seed=0):
     from oracle import logmel as OL
     from tests.test_gpu_ops import synth_pcm
 
-    g = GEOMETRIES[geom_name]
+    g = GEOMETRIES[geom_name] if isinstance(geom_name, str) else geom_name
     if n_layers_cut is not None:
         import dataclasses
         g = dataclasses.replace(g, n_layers=n_layers_cut)
@@ -52,6 +52,13 @@ def _run_case(geom_name, n_list, n_layers_cut=None, seed=0):
 
 def test_encoder_tiny_ragged_batch():
     _run_case("GTINY", [48000, 16000, 31999])
+
+
+def test_encoder_head_size_128():
+    """The head size of the 7B geometry (d / heads = 128) at a small width, ragged batch."""
+    import dataclasses
+    from omnilingual_asr.weights import GEOMETRIES
+    _run_case(dataclasses.replace(GEOMETRIES["GTINY"], name="GTINY-h128", n_heads=4), [48000, 16000, 80000], seed=6)
 
 
 def test_encoder_g300_two_layers_30s():

@@ -219,10 +219,10 @@ def _attention_ref(qkv, dist_emb, lengths, n_heads, left, right):
     return (p @ v).transpose(1, 2).reshape(b, t, d)
 
 
-def _prescale_q(qkv, d):
-    """The kernel takes q * log2(e) / sqrt(64), rounded to bf16: returns (device qkv, the float qkv whose
+def _prescale_q(qkv, d, head=64):
+    """The kernel takes q * log2(e) / sqrt(head), rounded to bf16: returns (device qkv, the float qkv whose
     q is exactly that rounded value scaled back, for the reference)."""
-    cs = 1.4426950408889634 / 8.0
+    cs = 1.4426950408889634 / math.sqrt(head)
     dev = qkv.clone().float()
     dev[..., :d] = dev[..., :d] * cs
     dev = _bf(dev)
@@ -231,15 +231,16 @@ def _prescale_q(qkv, d):
     return dev, ref
 
 
-@pytest.mark.parametrize("batch,t_pad,lens,heads", [(2, 256, [256, 131], 2), (1, 1504, [1499], 1),
-                                                    (3, 96, [96, 1, 70], 4)])
-def test_attention_relkey(batch, t_pad, lens, heads):
+@pytest.mark.parametrize("batch,t_pad,lens,heads,head", [
+    (2, 256, [256, 131], 2, 64), (1, 1504, [1499], 1, 64), (3, 96, [96, 1, 70], 4, 64),
+    (2, 256, [256, 131], 2, 128), (1, 1504, [1499], 1, 128), (3, 96, [96, 1, 70], 3, 128), (2, 544, [300, 544], 2, 128)])
+def test_attention_relkey(batch, t_pad, lens, heads, head):
     H = _lib()
     g = torch.Generator().manual_seed(t_pad + heads)
-    d = heads * 64
-    qkv, qkv_ref = _prescale_q(torch.randn((batch, t_pad, 3 * d), generator=g), d)
-    emb = torch.zeros((96, 64))
-    emb[:73] = torch.randn((73, 64), generator=g)
+    d = heads * head
+    qkv, qkv_ref = _prescale_q(torch.randn((batch, t_pad, 3 * d), generator=g), d, head)
+    emb = torch.zeros((96, head))
+    emb[:73] = torch.randn((73, head), generator=g) * (8.0 / math.sqrt(head))
     emb = _bf(emb)
     lengths = torch.tensor(lens, dtype=torch.int32)
     rows = (batch * t_pad + 255) // 256 * 256
@@ -248,7 +249,7 @@ def test_attention_relkey(batch, t_pad, lens, heads):
     ctx = torch.zeros((rows, d), dtype=torch.bfloat16, device="cuda")
     emb_d, len_d = emb.cuda(), lengths.cuda()
     H.check(H.lib().oasr_attention_relkey(qkv_d.data_ptr(), emb_d.data_ptr(), len_d.data_ptr(),
-                                          ctx.data_ptr(), batch, t_pad, heads, 64, 8, _stream()))
+                                          ctx.data_ptr(), batch, t_pad, heads, head, 64, 8, _stream()))
     torch.cuda.synchronize()
     ref = _attention_ref(qkv_ref, emb.float()[:73], lengths.long(), heads, 64, 8)
     got = ctx[: batch * t_pad].float().cpu().reshape(batch, t_pad, d).double()
@@ -258,22 +259,23 @@ def test_attention_relkey(batch, t_pad, lens, heads):
     assert torch.isfinite(got).all()
 
 
-def test_attention_online_softmax_rescale_is_exercised():
+@pytest.mark.parametrize("d", [64, 128])
+def test_attention_online_softmax_rescale_is_exercised(d):
     """A key late in the sequence that dominates every row forces the running maximum to jump at a
     later tile, so the rescale of the accumulated output is actually taken."""
     H = _lib()
-    batch, t_pad, heads, d = 1, 256, 1, 64
+    batch, t_pad, heads = 1, 256, 1
     g = torch.Generator().manual_seed(5)
     qkv = torch.randn((batch, t_pad, 3 * d), generator=g) * 0.5
     qkv[0, :, :d] = qkv[0, :, :d].abs()                 # positive queries
     qkv[0, 200, d:2 * d] = 6.0                          # one key with a large positive dot product
-    qkv, qkv_ref = _prescale_q(qkv, d)
-    emb = _bf(torch.zeros((96, 64)))
+    qkv, qkv_ref = _prescale_q(qkv, d, d)
+    emb = _bf(torch.zeros((96, d)))
     lengths = torch.tensor([t_pad], dtype=torch.int32)
     ctx = torch.zeros((256, d), dtype=torch.bfloat16, device="cuda")
     qkv_d, emb_d, len_d = qkv.reshape(-1, 3 * d).cuda(), emb.cuda(), lengths.cuda()
     H.check(H.lib().oasr_attention_relkey(qkv_d.data_ptr(), emb_d.data_ptr(), len_d.data_ptr(), ctx.data_ptr(),
-                                          batch, t_pad, heads, 64, 8, _stream()))
+                                          batch, t_pad, heads, d, 64, 8, _stream()))
     torch.cuda.synchronize()
     ref = _attention_ref(qkv_ref, emb.float()[:73], lengths.long(), heads, 64, 8)
     torch.testing.assert_close(ctx.float().cpu().reshape(1, t_pad, d).double(), ref, atol=3e-2, rtol=3e-2)

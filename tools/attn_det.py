@@ -11,7 +11,7 @@ for (batch,t_pad,heads,lens) in [(2,128,8,[124,99]),(3,1504,2,[1499,700,64])]:
     outs=[]
     for i in range(6):
         ctx=torch.zeros((rows,d),dtype=torch.bfloat16,device='cuda')
-        rc=lib.oasr_attention_relkey(qkv.data_ptr(),emb.data_ptr(),ln.data_ptr(),ctx.data_ptr(),batch,t_pad,heads,64,8,torch.cuda.current_stream().cuda_stream)
+        rc=lib.oasr_attention_relkey(qkv.data_ptr(),emb.data_ptr(),ln.data_ptr(),ctx.data_ptr(),batch,t_pad,heads,64,64,8,torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize(); outs.append(ctx)
     for i in range(1,6):
         diff=(outs[i].float()-outs[0].float()).abs()
