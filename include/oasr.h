@@ -225,6 +225,14 @@ int oasr_gemm_bf16(const uint16_t* a, const uint16_t* w, const float* bias, cons
                    void* c, int64_t m, int64_t n, int64_t k, float alpha, int32_t epilogue,
                    void* stream);
 
+/* LayerNorm (optionally followed by Swish) straight to e4m3 rows + per-row scale: byte-identical to
+ * oasr_layernorm(out_bf16=1) followed by oasr_quant_fp8_rows, without the intermediate bf16 matrix.
+ * oasr_layernorm2_fp8 is the same for oasr_layernorm2 (x is overwritten with its first LayerNorm). */
+int oasr_layernorm_fp8(const float* x, const float* w, const float* b, uint8_t* y, float* scale,
+                       int64_t rows, int32_t d, float eps, int32_t swish, void* stream);
+int oasr_layernorm2_fp8(float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                        uint8_t* y, float* scale, int64_t rows, int32_t d, float eps, void* stream);
+
 /* fp8 path (OCP e4m3).  y[r][:] = e4m3(x[r][:] / scale[r]), scale[r] = max|x[r]| / 448 (1 for an
  * all-zero row); x bf16 [rows][k], k a multiple of 8. */
 int oasr_quant_fp8_rows(const uint16_t* x, int64_t rows, int64_t k, uint8_t* y, float* scale,

@@ -142,53 +142,66 @@ int oasr_encoder_forward(const oasr_encoder* enc, const float* feats, const int3
     OASR_TRY(oasr_gemm_bf16(ws.big, enc->top.fp_w, enc->top.fp_b, nullptr, x, rows, d, kFeatK, 1.0f,
                             OASR_EPI_BIAS_F32, stream));
     // one large projection: bf16 GEMM, or row quantisation + fp8 GEMM when fp8 weights are set
+    // `a` = nullptr: the operand already sits in ws.a8 / ws.sa (written by a LayerNorm of the fp8 path)
     auto project = [&](const uint16_t* a, int64_t k, const uint16_t* wb, const uint8_t* wq, const float* wscale,
                        const float* bias, const float* resid, void* dst, int64_t n, float alpha, int epi) -> int {
         if (!fp8) return oasr_gemm_bf16(a, wb, bias, resid, dst, rows, n, k, alpha, epi, stream);
-        OASR_TRY(oasr_quant_fp8_rows(a, rows, k, ws.a8, ws.sa, stream));
+        if (a) OASR_TRY(oasr_quant_fp8_rows(a, rows, k, ws.a8, ws.sa, stream));
         return oasr_gemm_fp8(ws.a8, wq, ws.sa, wscale, bias, resid, dst, rows, n, k, alpha, epi, stream);
     };
+    // LayerNorm feeding a projection: bf16 rows in ws.xn, or (fp8 path) e4m3 rows + scales in ws.a8 / ws.sa
+    auto norm = [&](const float* src, const float* lw, const float* lb, int64_t nrows, int swish) -> int {
+        if (fp8) return oasr_layernorm_fp8(src, lw, lb, ws.a8, ws.sa, nrows, d, c.ln_eps, swish, stream);
+        return oasr_layernorm(src, lw, lb, ws.xn, nrows, d, d, c.ln_eps, 1, swish, stream);
+    };
+    const uint16_t* xn = fp8 ? nullptr : ws.xn;
     static const oasr_layer_fp8_weights kNoFp8 = {};
     for (int l = 0; l < nl; ++l) {
         const oasr_layer_weights& w = enc->layers[l];
         const oasr_layer_fp8_weights& q = fp8 ? enc->fp8[l] : kNoFp8;
-        if (l == 0)
-            OASR_TRY(oasr_layernorm(x, w.ffn1_ln_w, w.ffn1_ln_b, ws.xn, rows, d, d, c.ln_eps, 1, 0, stream));
+        if (l == 0) OASR_TRY(norm(x, w.ffn1_ln_w, w.ffn1_ln_b, rows, 0));
         // half-step feed-forward 1
-        OASR_TRY(project(ws.xn, d, w.ffn1_w1, q.ffn1_w1_q, q.ffn1_w1_s, w.ffn1_b1, nullptr, ws.big, f, 1.0f,
+        OASR_TRY(project(xn, d, w.ffn1_w1, q.ffn1_w1_q, q.ffn1_w1_s, w.ffn1_b1, nullptr, ws.big, f, 1.0f,
                          OASR_EPI_BIAS_SWISH_BF16));
         OASR_TRY(project(ws.big, f, w.ffn1_w2, q.ffn1_w2_q, q.ffn1_w2_s, w.ffn1_b2, x, x, d, 0.5f,
                          OASR_EPI_RESIDUAL_F32));
         // self-attention
-        OASR_TRY(oasr_layernorm(x, w.attn_ln_w, w.attn_ln_b, ws.xn, rows, d, d, c.ln_eps, 1, 0, stream));
-        OASR_TRY(project(ws.xn, d, w.wqkv, q.wqkv_q, q.wqkv_s, w.bqkv, nullptr, ws.big, 3 * (int64_t)d, 1.0f,
+        OASR_TRY(norm(x, w.attn_ln_w, w.attn_ln_b, rows, 0));
+        OASR_TRY(project(xn, d, w.wqkv, q.wqkv_q, q.wqkv_s, w.bqkv, nullptr, ws.big, 3 * (int64_t)d, 1.0f,
                          OASR_EPI_BIAS_BF16));
         OASR_TRY(oasr_attention_relkey(ws.big, w.dist_emb, lengths, ws.ctx, batch, t_pad, c.n_heads,
                                        c.d_model / c.n_heads, c.left_max, c.right_max, stream));
         OASR_TRY(project(ws.ctx, d, w.wo, q.wo_q, q.wo_s, w.bo, x, x, d, 1.0f, OASR_EPI_RESIDUAL_F32));
         // convolution module
-        OASR_TRY(oasr_layernorm(x, w.conv_ln_w, w.conv_ln_b, ws.xn, rows, d, d, c.ln_eps, 1, 0, stream));
-        OASR_TRY(project(ws.xn, d, w.pw1, q.pw1_q, q.pw1_s, nullptr, nullptr, ws.ctx, 2 * (int64_t)d, 1.0f,
+        OASR_TRY(norm(x, w.conv_ln_w, w.conv_ln_b, rows, 0));
+        OASR_TRY(project(xn, d, w.pw1, q.pw1_q, q.pw1_s, nullptr, nullptr, ws.ctx, 2 * (int64_t)d, 1.0f,
                          OASR_EPI_GLU_BF16));
         if (c.conv_kernel == 31 && (d == 512 || d == 1024 || d == 2048) && t_pad % 16 == 0) {
             OASR_TRY(oasr_dwconv_ln_swish(ws.ctx, w.dw, w.dw_ln_w, w.dw_ln_b, ws.xn, batch, t_pad, d,
                                           c.conv_kernel, c.ln_eps, stream));
+            OASR_TRY(project(ws.xn, d, w.pw2, q.pw2_q, q.pw2_s, nullptr, x, x, d, 1.0f, OASR_EPI_RESIDUAL_F32));
         } else {
+            // rows past batch * t_pad keep the bytes of an earlier operand (finite; their products are
+            // never read)
             OASR_TRY(oasr_dwconv_causal(ws.ctx, w.dw, ws.tmp, batch, t_pad, d, c.conv_kernel, stream));
-            OASR_TRY(oasr_layernorm(ws.tmp, w.dw_ln_w, w.dw_ln_b, ws.xn, live, d, d, c.ln_eps, 1, 1, stream));
+            OASR_TRY(norm(ws.tmp, w.dw_ln_w, w.dw_ln_b, live, 1));
+            OASR_TRY(project(xn, d, w.pw2, q.pw2_q, q.pw2_s, nullptr, x, x, d, 1.0f, OASR_EPI_RESIDUAL_F32));
         }
-        OASR_TRY(project(ws.xn, d, w.pw2, q.pw2_q, q.pw2_s, nullptr, x, x, d, 1.0f, OASR_EPI_RESIDUAL_F32));
         // half-step feed-forward 2
-        OASR_TRY(oasr_layernorm(x, w.ffn2_ln_w, w.ffn2_ln_b, ws.xn, rows, d, d, c.ln_eps, 1, 0, stream));
-        OASR_TRY(project(ws.xn, d, w.ffn2_w1, q.ffn2_w1_q, q.ffn2_w1_s, w.ffn2_b1, nullptr, ws.big, f, 1.0f,
+        OASR_TRY(norm(x, w.ffn2_ln_w, w.ffn2_ln_b, rows, 0));
+        OASR_TRY(project(xn, d, w.ffn2_w1, q.ffn2_w1_q, q.ffn2_w1_s, w.ffn2_b1, nullptr, ws.big, f, 1.0f,
                          OASR_EPI_BIAS_SWISH_BF16));
         OASR_TRY(project(ws.big, f, w.ffn2_w2, q.ffn2_w2_q, q.ffn2_w2_s, w.ffn2_b2, x, x, d, 0.5f,
                          OASR_EPI_RESIDUAL_F32));
         // block output LayerNorm, fused with the next block's first LayerNorm when there is one
         if (l + 1 < nl) {
             const oasr_layer_weights& nx = enc->layers[l + 1];
-            OASR_TRY(oasr_layernorm2(x, w.final_ln_w, w.final_ln_b, nx.ffn1_ln_w, nx.ffn1_ln_b, ws.xn, rows, d,
-                                     c.ln_eps, stream));
+            if (fp8)
+                OASR_TRY(oasr_layernorm2_fp8(x, w.final_ln_w, w.final_ln_b, nx.ffn1_ln_w, nx.ffn1_ln_b, ws.a8, ws.sa,
+                                             rows, d, c.ln_eps, stream));
+            else
+                OASR_TRY(oasr_layernorm2(x, w.final_ln_w, w.final_ln_b, nx.ffn1_ln_w, nx.ffn1_ln_b, ws.xn, rows, d,
+                                         c.ln_eps, stream));
         } else {
             OASR_TRY(oasr_layernorm(x, w.final_ln_w, w.final_ln_b, x, rows, d, d, c.ln_eps, 0, 0, stream));
         }

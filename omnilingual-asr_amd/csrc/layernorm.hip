@@ -72,6 +72,86 @@ __global__ __launch_bounds__(256) void layernorm2_kernel(float* __restrict__ x,
     }
 }
 
+// e4m3 output for the fp8 projections: the normalised row is rounded to bf16 first (so the bytes equal
+// what the bf16 kernel followed by the row quantiser produces), then scale = max|row| / 448 (1 for an
+// all-zero row) and y = e4m3(row / scale).  Saves the quantiser's sweep: 1 byte out instead of 2 out,
+// 2 in, 1 out per element.
+template <int VPL>
+__device__ __forceinline__ void store_row_fp8(float4 (&v)[VPL], uint8_t* __restrict__ yr, float* __restrict__ scale,
+                                              int64_t row, int lane) {
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < VPL; ++c) {
+        const uint32_t lo = pack_bf16x2(v[c].x, v[c].y), hi = pack_bf16x2(v[c].z, v[c].w);
+        v[c].x = __uint_as_float(lo << 16);
+        v[c].y = __uint_as_float(lo & 0xFFFF0000u);
+        v[c].z = __uint_as_float(hi << 16);
+        v[c].w = __uint_as_float(hi & 0xFFFF0000u);
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[c].x), fabsf(v[c].y))), fmaxf(fabsf(v[c].z), fabsf(v[c].w)));
+    }
+    amax = wave_max(amax);
+    const float s = amax > 0.f ? amax / 448.0f : 1.0f;
+    const float inv = 1.0f / s;
+    if (lane == 0) scale[row] = s;
+#pragma unroll
+    for (int c = 0; c < VPL; ++c) {
+        int pk = 0;
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[c].x * inv, v[c].y * inv, pk, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[c].z * inv, v[c].w * inv, pk, true);
+        *reinterpret_cast<uint32_t*>(yr + 4 * lane + 256 * c) = (uint32_t)pk;
+    }
+}
+
+template <int VPL, bool SWISH>
+__global__ __launch_bounds__(256) void layernorm_fp8_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, uint8_t* __restrict__ y,
+                                                            float* __restrict__ scale, int64_t rows, float eps) {
+    constexpr int D = 256 * VPL;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * D;
+    float4 v[VPL];
+#pragma unroll
+    for (int c = 0; c < VPL; ++c) v[c] = *reinterpret_cast<const float4*>(xr + 4 * lane + 256 * c);
+    float mean, rstd;
+    row_stats<VPL>(v, mean, rstd, eps);
+    row_affine<VPL>(v, mean, rstd, w, b, lane);
+    if (SWISH) {
+#pragma unroll
+        for (int c = 0; c < VPL; ++c) {
+            v[c].x = swishf(v[c].x);
+            v[c].y = swishf(v[c].y);
+            v[c].z = swishf(v[c].z);
+            v[c].w = swishf(v[c].w);
+        }
+    }
+    store_row_fp8<VPL>(v, y + row * D, scale, row, lane);
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void layernorm2_fp8_kernel(float* __restrict__ x, const float* __restrict__ w1,
+                                                             const float* __restrict__ b1, const float* __restrict__ w2,
+                                                             const float* __restrict__ b2, uint8_t* __restrict__ y,
+                                                             float* __restrict__ scale, int64_t rows, float eps) {
+    constexpr int D = 256 * VPL;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* xr = x + row * D;
+    float4 v[VPL];
+#pragma unroll
+    for (int c = 0; c < VPL; ++c) v[c] = *reinterpret_cast<const float4*>(xr + 4 * lane + 256 * c);
+    float mean, rstd;
+    row_stats<VPL>(v, mean, rstd, eps);
+    row_affine<VPL>(v, mean, rstd, w1, b1, lane);
+#pragma unroll
+    for (int c = 0; c < VPL; ++c) *reinterpret_cast<float4*>(xr + 4 * lane + 256 * c) = v[c];
+    row_stats<VPL>(v, mean, rstd, eps);
+    row_affine<VPL>(v, mean, rstd, w2, b2, lane);
+    store_row_fp8<VPL>(v, y + row * D, scale, row, lane);
+}
+
 // d = 160 (the stacked feature rows): 40 float4 per row on lanes 0..39; output row pitch
 // y_stride >= 160 with the tail zero-filled so it can feed a GEMM whose K is padded to 192.
 template <bool OUT_BF16>
@@ -164,6 +244,56 @@ int oasr_layernorm(const float* x, const float* w, const float* b, void* y, int6
         }
     }
     OASR_CHECK_LAUNCH("layernorm");
+    return OASR_OK;
+}
+
+int oasr_layernorm_fp8(const float* x, const float* w, const float* b, uint8_t* y, float* scale, int64_t rows,
+                       int32_t d, float eps, int32_t swish, void* stream) {
+    OASR_REQUIRE(x && w && b && y && scale, "layernorm_fp8: null pointer");
+    OASR_REQUIRE(rows > 0 && rows < ((int64_t)1 << 33), "layernorm_fp8: bad row count");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)((rows + 3) / 4)), blk(256);
+#define OASR_LN8(V)                                                                                              \
+    do {                                                                                                         \
+        if (swish)                                                                                               \
+            hipLaunchKernelGGL((layernorm_fp8_kernel<V, true>), grid, blk, 0, st, x, w, b, y, scale, rows, eps); \
+        else                                                                                                     \
+            hipLaunchKernelGGL((layernorm_fp8_kernel<V, false>), grid, blk, 0, st, x, w, b, y, scale, rows, eps); \
+    } while (0)
+    switch (d) {
+        case 256: OASR_LN8(1); break;
+        case 512: OASR_LN8(2); break;
+        case 1024: OASR_LN8(4); break;
+        case 2048: OASR_LN8(8); break;
+        case 4096: OASR_LN8(16); break;
+        default:
+            set_error("layernorm_fp8: unsupported width %d (256, 512, 1024, 2048, 4096)", d);
+            return OASR_EINVAL;
+    }
+#undef OASR_LN8
+    OASR_CHECK_LAUNCH("layernorm_fp8");
+    return OASR_OK;
+}
+
+int oasr_layernorm2_fp8(float* x, const float* w1, const float* b1, const float* w2, const float* b2, uint8_t* y,
+                        float* scale, int64_t rows, int32_t d, float eps, void* stream) {
+    OASR_REQUIRE(x && w1 && b1 && w2 && b2 && y && scale, "layernorm2_fp8: null pointer");
+    OASR_REQUIRE(rows > 0 && rows < ((int64_t)1 << 33), "layernorm2_fp8: bad row count");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)((rows + 3) / 4)), blk(256);
+#define OASR_LN28(V) hipLaunchKernelGGL((layernorm2_fp8_kernel<V>), grid, blk, 0, st, x, w1, b1, w2, b2, y, scale, rows, eps)
+    switch (d) {
+        case 256: OASR_LN28(1); break;
+        case 512: OASR_LN28(2); break;
+        case 1024: OASR_LN28(4); break;
+        case 2048: OASR_LN28(8); break;
+        case 4096: OASR_LN28(16); break;
+        default:
+            set_error("layernorm2_fp8: unsupported width %d (256, 512, 1024, 2048, 4096)", d);
+            return OASR_EINVAL;
+    }
+#undef OASR_LN28
+    OASR_CHECK_LAUNCH("layernorm2_fp8");
     return OASR_OK;
 }
 

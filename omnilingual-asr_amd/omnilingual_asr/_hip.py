@@ -87,6 +87,8 @@ _SIGNATURES = {
     "oasr_layernorm2": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_vp]),
     "oasr_gemm_bf16": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_i32, c_vp]),
     "oasr_encoder_set_fp8": (c_i32, [c_vp, c_vp]),
+    "oasr_layernorm_fp8": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_i32, c_vp]),
+    "oasr_layernorm2_fp8": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_vp]),
     "oasr_quant_fp8_rows": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "oasr_gemm_fp8": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_i32, c_vp]),
     "oasr_attention_relkey": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),

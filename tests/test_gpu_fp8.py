@@ -57,6 +57,39 @@ def test_quant_fp8_rows(rows, k):
     assert got.abs().max() <= 448
 
 
+@pytest.mark.parametrize("rows,d,swish", [(9, 512, 0), (130, 1024, 0), (6, 4096, 1), (5, 2048, 1), (3, 256, 0)])
+def test_layernorm_fp8_equals_layernorm_then_quant(rows, d, swish):
+    """The fused kernels must produce the very bytes and scales of the two-kernel sequence they replace."""
+    H = _lib()
+    g = torch.Generator().manual_seed(rows + d)
+    x = (torch.randn((rows, d), generator=g) * 3 + 0.5).cuda()
+    x[1] = 0.25                                   # constant row: normalises to the bias
+    w1, b1 = (torch.randn((d,), generator=g).cuda() for _ in range(2))
+    w2, b2 = (torch.randn((d,), generator=g).cuda() for _ in range(2))
+    L, st = H.lib(), _stream()
+    y_bf = torch.zeros((rows, d), dtype=torch.bfloat16, device="cuda")
+    q_ref = torch.zeros((rows, d), dtype=torch.uint8, device="cuda")
+    s_ref = torch.zeros((rows,), dtype=torch.float32, device="cuda")
+    q = torch.full((rows, d), 0x55, dtype=torch.uint8, device="cuda")
+    sc = torch.zeros((rows,), dtype=torch.float32, device="cuda")
+    H.check(L.oasr_layernorm(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), y_bf.data_ptr(), rows, d, d, 1e-5, 1, swish, st))
+    H.check(L.oasr_quant_fp8_rows(y_bf.data_ptr(), rows, d, q_ref.data_ptr(), s_ref.data_ptr(), st))
+    H.check(L.oasr_layernorm_fp8(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), q.data_ptr(), sc.data_ptr(), rows, d, 1e-5, swish, st))
+    torch.cuda.synchronize()
+    assert torch.equal(q, q_ref) and torch.equal(sc, s_ref)
+    if not swish:
+        xa, xb = x.clone(), x.clone()
+        H.check(L.oasr_layernorm2(xa.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                  y_bf.data_ptr(), rows, d, 1e-5, st))
+        H.check(L.oasr_quant_fp8_rows(y_bf.data_ptr(), rows, d, q_ref.data_ptr(), s_ref.data_ptr(), st))
+        H.check(L.oasr_layernorm2_fp8(xb.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                      q.data_ptr(), sc.data_ptr(), rows, d, 1e-5, st))
+        torch.cuda.synchronize()
+        assert torch.equal(xa, xb) and torch.equal(q, q_ref) and torch.equal(sc, s_ref)
+    rc = L.oasr_layernorm_fp8(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), q.data_ptr(), sc.data_ptr(), rows, 160, 1e-5, 0, st)
+    assert rc == -1 and b"unsupported width" in L.oasr_last_error()
+
+
 @pytest.mark.parametrize("m,n,k,epi", [
     (256, 256, 64, 0), (512, 768, 1024, 0), (512, 512, 512, 1), (256, 512, 1024, 2), (512, 256, 2048, 3),
     (256, 256, 192, 4), (4096, 1024, 1024, 3), (5120, 1024, 512, 1),
