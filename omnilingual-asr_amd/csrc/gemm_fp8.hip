@@ -354,6 +354,46 @@ __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const uint16_t* __r
     }
 }
 
+// Same result with the row held in registers (k = 512 NV, NV 16-byte loads per lane, all issued before
+// the first use): one sweep over memory and NV loads in flight per lane instead of one.
+template <int NV>
+__global__ __launch_bounds__(256) void quant_fp8_rows_reg_kernel(const uint16_t* __restrict__ x, int64_t rows,
+                                                                 uint8_t* __restrict__ y, float* __restrict__ scale) {
+    constexpr int64_t K = 512 * NV;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const uint16_t* xr = x + row * K + 8 * lane;
+    u32x4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xr + 512 * i));
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const uint32_t w[4] = {v[i][0], v[i][1], v[i][2], v[i][3]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            amax = fmaxf(amax, fabsf(__uint_as_float(w[q] << 16)));
+            amax = fmaxf(amax, fabsf(__uint_as_float(w[q] & 0xFFFF0000u)));
+        }
+    }
+    amax = wave_max(amax);
+    const float s = amax > 0.f ? amax / 448.0f : 1.0f;
+    const float inv = 1.0f / s;
+    if (lane == 0) scale[row] = s;
+    uint8_t* yr = y + row * K + 8 * lane;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const uint32_t w[4] = {v[i][0], v[i][1], v[i][2], v[i][3]};
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(w[0] << 16) * inv, __uint_as_float(w[0] & 0xFFFF0000u) * inv, lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(w[1] << 16) * inv, __uint_as_float(w[1] & 0xFFFF0000u) * inv, lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(w[2] << 16) * inv, __uint_as_float(w[2] & 0xFFFF0000u) * inv, hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(w[3] << 16) * inv, __uint_as_float(w[3] & 0xFFFF0000u) * inv, hi, true);
+        *reinterpret_cast<uint2*>(yr + 512 * i) = make_uint2((uint32_t)lo, (uint32_t)hi);
+    }
+}
+
 }  // namespace f8
 }  // namespace oasr
 
@@ -366,8 +406,16 @@ extern "C" int oasr_quant_fp8_rows(const uint16_t* x, int64_t rows, int64_t k, u
     OASR_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 7) == 0, "quant_fp8_rows: misaligned pointer");
     const int64_t blocks = (rows + 3) / 4;
     OASR_REQUIRE(blocks < ((int64_t)1 << 31), "quant_fp8_rows: too many rows");
-    hipLaunchKernelGGL(f8::quant_fp8_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, rows,
-                       k, y, scale);
+    const dim3 grid((unsigned)blocks), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (k) {   // widths of the encoder geometries keep the row in registers
+        case 1024: hipLaunchKernelGGL(f8::quant_fp8_rows_reg_kernel<2>, grid, blk, 0, st, x, rows, y, scale); break;
+        case 2048: hipLaunchKernelGGL(f8::quant_fp8_rows_reg_kernel<4>, grid, blk, 0, st, x, rows, y, scale); break;
+        case 4096: hipLaunchKernelGGL(f8::quant_fp8_rows_reg_kernel<8>, grid, blk, 0, st, x, rows, y, scale); break;
+        case 8192: hipLaunchKernelGGL(f8::quant_fp8_rows_reg_kernel<16>, grid, blk, 0, st, x, rows, y, scale); break;
+        case 16384: hipLaunchKernelGGL(f8::quant_fp8_rows_reg_kernel<32>, grid, blk, 0, st, x, rows, y, scale); break;
+        default: hipLaunchKernelGGL(f8::quant_fp8_rows_kernel, grid, blk, 0, st, x, rows, k, y, scale);
+    }
     OASR_CHECK_LAUNCH("quant_fp8_rows");
     return OASR_OK;
 }

@@ -39,7 +39,7 @@ def _quant_device(x_bf16: torch.Tensor):
     return y, s
 
 
-@pytest.mark.parametrize("rows,k", [(7, 512), (256, 1024), (33, 4096), (5, 8)])
+@pytest.mark.parametrize("rows,k", [(7, 512), (256, 1024), (33, 4096), (5, 8), (9, 16384), (6, 2048), (5, 8192), (4, 1536)])
 def test_quant_fp8_rows(rows, k):
     g = torch.Generator().manual_seed(rows + k)
     x = (torch.randn((rows, k), generator=g) * torch.rand((rows, 1), generator=g) * 4).to(torch.bfloat16)
