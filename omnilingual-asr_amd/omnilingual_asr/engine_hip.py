@@ -308,8 +308,12 @@ class HipEngine:
                 "counts": pin((b,), torch.int32), "lengths": pin((b,), torch.int32), "acts": pin((b,), torch.float64),
                 "copied": torch.cuda.Event(), "done": torch.cuda.Event(), "busy": False,
             }
+            # the zero fills above are queued on the current stream, possibly behind a whole batch: the copy
+            # stream waits for `done` before it writes the slot, so mark the fills as the slot's first use
+            t["done"].record()
             if len(self._tickets) >= 6:         # full batches and one tail shape, two slots each
-                self._tickets.pop(next(iter(self._tickets)))
+                old = self._tickets.pop(next(iter(self._tickets)))
+                old["done"].synchronize()       # nothing may still be reading buffers about to be freed
             self._tickets[key] = t
         return t
 

@@ -148,6 +148,9 @@ def forward(feats, lengths, weights: dict, g: Geometry = G300, dtype=torch.float
     """weights: {'fp_ln_w','fp_ln_b','fp_w','fp_b','layers': [ {LAYER_KEYS...} ]}.
     Returns hidden [B, T, d] (and the list of per-layer outputs when per_layer)."""
     cast = lambda t: t.to(dtype)
+    if feats.shape[1] == 0:     # audio shorter than two frames: no encoder rows at all
+        x = torch.zeros((feats.shape[0], 0, g.d_model), dtype=dtype)
+        return (x, [x] * (len(weights["layers"]) + 1)) if per_layer else x
     top = {k: cast(v) for k, v in weights.items() if k != "layers"}
     x = input_projection(cast(feats), top, g)
     outs = [x]

@@ -115,3 +115,20 @@ def test_two_deep_chunk_loop_equals_batch_at_a_time():
                 assert r.activity == acts[i]
                 np.testing.assert_array_equal(r.tokens, toks[i][0])
                 np.testing.assert_array_equal(r.frames, toks[i][1])
+
+
+@pytest.mark.parametrize("n,end", [(0, 1.0), (100, 100 / 16000.0), (400, 0.025), (720, 0.045)])
+def test_audio_shorter_than_the_first_stacked_frame_on_hip(tmp_path, n, end):
+    """Empty and sub-frame files through the HIP engine: zero encoder frames, no exception, empty text."""
+    from omnilingual_asr import Pipeline
+
+    path = tmp_path / "short.wav"
+    rng = np.random.default_rng(n)
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes((rng.standard_normal(n) * 3000).astype("<i2").tobytes())
+    pipe = Pipeline(model="GTINY", seed=1)
+    segs = pipe.transcribe(str(path), word_timestamps=True)
+    assert len(segs) == 1 and (segs[0].start, segs[0].end) == (0.0, end)
+    if n < 720:
+        assert segs[0].text == "" and segs[0].words == []

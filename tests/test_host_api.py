@@ -225,3 +225,18 @@ def test_split_audio_into_chunks_contract(tmp_path):
     assert [(p.name, s) for p, s in parts] == [("chunk_0000.wav", 0.0), ("chunk_0001.wav", 2.0), ("chunk_0002.wav", 4.0)]
     assert AP.get_audio_duration(parts[-1][0]) == pytest.approx(1.0)
     assert AP.split_audio_into_chunks(tmp_path / "missing.wav") == [(tmp_path / "missing.wav", 0.0)]
+
+
+@pytest.mark.parametrize("n,end", [(0, 1.0), (100, 100 / 16000.0), (400, 0.025), (720, 0.045)])
+def test_audio_shorter_than_the_first_stacked_frame(tmp_path, tiny_engine, n, end):
+    """Empty and sub-frame files: no exception; one segment with empty text until two 25 ms frames fit
+    (720 samples); a zero-length file gets the reference's end <= start fix-up (ref :396-397)."""
+    import wave
+    path = tmp_path / "short.wav"
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes((np.random.default_rng(n).standard_normal(n) * 3000).astype("<i2").tobytes())
+    segs = Pipeline(engine=tiny_engine).transcribe(str(path), word_timestamps=True)
+    assert len(segs) == 1 and (segs[0].start, segs[0].end) == (0.0, end)
+    if n < 720:
+        assert segs[0].text == "" and segs[0].words == []
