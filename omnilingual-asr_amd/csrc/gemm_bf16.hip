@@ -330,11 +330,20 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(const uint16_t* __restri
             OASR_RAW_BARRIER();
             // ---- MFMA segment
             __builtin_amdgcn_s_setprio(1);
+            if (t == 0) {   // a tile's first slice starts from a constant zero: no accumulator clearing pass
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ii = 0; ii < 8; ++ii)
+                for (int ii = 0; ii < 8; ++ii)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[ii], acc[ii][j], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j)
+                        acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[ii], zero, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int ii = 0; ii < 8; ++ii)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[ii], acc[ii][j], 0, 0, 0);
+            }
             __builtin_amdgcn_s_setprio(0);
             // Group B holds the barrier that ends a tile's last MFMA segment until its epilogue is
             // done, so that the two groups' epilogues overlap instead of running one after the other
@@ -344,10 +353,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(const uint16_t* __restri
         gemm_epilogue<EPI>(acc, bv, resid, C, N, alpha, m0 + wm * 128, n0 + wn * 64, lane,
                            smem + 2 * kRing * kSliceBytes + wave * kEpiSlab);
         if (wm == 1) OASR_RAW_BARRIER();
-#pragma unroll
-        for (int ii = 0; ii < 8; ++ii)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[ii][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     if (wm == 0) OASR_RAW_BARRIER();  // same barrier count in both groups
 }

@@ -199,13 +199,13 @@ __global__ __launch_bounds__(512) void gemm_fp8_kernel(const uint8_t* __restrict
     if (slot >= local_tiles) return;
     const int my_tiles = (local_tiles - slot + per_xcd - 1) / per_xcd;  // local tiles slot + i*per_xcd
 
-    f32x16 acc[4][2];
+    f32x16 acc[4][2], zero16;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) zero16[e] = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int j = 0; j < 2; ++j) acc[i][j] = zero16;
 
     const int nph = (int)(K / BK);          // phases (K slices) per output tile
     const int total = my_tiles * nph;
@@ -300,7 +300,9 @@ __global__ __launch_bounds__(512) void gemm_fp8_kernel(const uint8_t* __restrict
                 for (int j = 0; j < 2; ++j) {
                     const i32x8 wf = {(int)w0[j][0], (int)w0[j][1], (int)w0[j][2], (int)w0[j][3],
                                       (int)w1[j][0], (int)w1[j][1], (int)w1[j][2], (int)w1[j][3]};
-                    acc[ii][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf, xf, acc[ii][j], 0, 0, 0, 0, 0, 0);
+                    // a tile's first slice starts from a constant zero: no accumulator clearing pass
+                    acc[ii][j] = t == 0 ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf, xf, zero16, 0, 0, 0, 0, 0, 0)
+                                        : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf, xf, acc[ii][j], 0, 0, 0, 0, 0, 0);
                 }
             }
             __builtin_amdgcn_s_setprio(0);
@@ -308,12 +310,6 @@ __global__ __launch_bounds__(512) void gemm_fp8_kernel(const uint8_t* __restrict
         }
         epilogue<EPI>(acc, sam, swv, bv, resid, C, N, alpha, m0 + wm * 128, n0 + wn * 64, lane, slab);
         if (wm == 1) OASR8_RAW_BARRIER();
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[ii][j][e] = 0.f;
     }
     if (wm == 0) OASR8_RAW_BARRIER();  // same barrier count in both groups
 }
