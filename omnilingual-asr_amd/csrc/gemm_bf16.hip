@@ -97,27 +97,24 @@ __device__ __forceinline__ void stage_slice(const char* __restrict__ src, uint32
     }
 }
 
-// Bias values of one output tile in the layout its epilogue consumes: per fragment column for the
-// bf16 epilogues (bv[j] = bias[nbase + 16 j + 4 fq ..]), per read-back chunk for the float32 ones
-// (bv[h] = bias[nbase + 32 h + 4 (lane & 7) ..]).  Loaded at the start of a tile so that the
-// epilogue does not begin with a memory round trip.
-template <int EPI>
-__device__ __forceinline__ void load_bias(float4 (&bv)[4], const float* __restrict__ bias, int64_t nbase, int lane) {
-    if (EPI == OASR_EPI_GLU_BF16) return;
-    if (EPI == OASR_EPI_BIAS_BF16 || EPI == OASR_EPI_BIAS_SWISH_BF16) {
+// Bias.  The 64 bias values of a wave's 64 output columns reach the accumulators without touching the
+// vector ALU: one 4-byte-per-lane global_load_lds puts them into a wave-private LDS strip (two
+// strips, alternating by tile, 256 bytes each), issued one K slice before the tile starts so that the
+// in-order vmcnt wait of the tile's first LOAD segment covers it; after that wait the wave reads
+// bv[j] = bias[nbase + 16 j + 4 fq ..] (the four consecutive n a lane holds in acc[.][j]) and the
+// tile's first MFMAs take bv[j] as their C operand.  No bias (or the GLU epilogue): bv = 0.
+__device__ __forceinline__ void bias_to_lds(const float* __restrict__ bias, int64_t nbase, int lane, char* strip) {
+    __builtin_amdgcn_global_load_lds((gbl_void*)(bias + nbase + lane), (lds_void*)strip, 4, 0, 0);
+}
+
+__device__ __forceinline__ void bias_from_lds(f32x4 (&bv)[4], const char* strip, int lane) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            bv[j] = bias ? *reinterpret_cast<const float4*>(bias + nbase + j * 16 + (lane >> 4) * 4) : make_float4(0, 0, 0, 0);
-    } else {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            bv[h] = bias ? *reinterpret_cast<const float4*>(bias + nbase + h * 32 + (lane & 7) * 4) : make_float4(0, 0, 0, 0);
-    }
+    for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const f32x4*>(strip + (j * 16 + (lane >> 4) * 4) * 4);
 }
 
 // acc[i][j]: lane (fr = lane & 15, fq = lane >> 4) holds C[mbase + 16 i + fr][nbase + 16 j + 4 fq + 0..3].
 template <int EPI>
-__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[8][4], const float4 (&bv)[4],
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[8][4],
                                               const float* resid, void* C, int64_t N, float alpha,
                                               int64_t mbase, int64_t nbase, int lane, char* slab) {
     const int fr = lane & 15, fq = lane >> 4;
@@ -129,7 +126,6 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[8][4], const float4 (
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 f32x4 v = acc[i][j];
-                v[0] += bv[j].x; v[1] += bv[j].y; v[2] += bv[j].z; v[3] += bv[j].w;
                 if (EPI == OASR_EPI_BIAS_SWISH_BF16) {
                     v[0] = swishf(v[0]); v[1] = swishf(v[1]); v[2] = swishf(v[2]); v[3] = swishf(v[3]);
                 }
@@ -198,7 +194,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[8][4], const float4 (
                 OASR_WAVE_LDS_SYNC();
 #pragma unroll
                 for (int r2 = 0; r2 < 2; ++r2) {
-                    float4 o = make_float4(v[r2].x + bv[h].x, v[r2].y + bv[h].y, v[r2].z + bv[h].z, v[r2].w + bv[h].w);
+                    float4 o = v[r2];
                     if (EPI == OASR_EPI_RESIDUAL_F32) {
                         const float4 r = rcur[h][r2];
                         o = make_float4(r.x + alpha * o.x, r.y + alpha * o.y, r.z + alpha * o.z, r.w + alpha * o.w);
@@ -223,7 +219,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(const uint16_t* __restri
                                                         const float* __restrict__ bias,
                                                         const float* resid, void* C, int64_t N,
                                                         int64_t K, float alpha, int n_tiles) {
-    __shared__ __attribute__((aligned(1024))) char smem[2 * kRing * kSliceBytes + 8 * kEpiSlab];  // A ring | W ring | slabs
+    // ONE object on purpose: with the ring in an array of its own the compiler orders every fragment
+    // read after all copies in flight (s_waitcnt vmcnt(0) per slice), which serialises the ring
+    __shared__ __attribute__((aligned(1024))) char smem[2 * kRing * kSliceBytes + 8 * kEpiSlab + 8 * 2 * 256];  // A ring | W ring | slabs | bias strips
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -296,6 +294,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(const uint16_t* __restri
     };
     stage_seek(0);
 
+    const bool has_bias = EPI != OASR_EPI_GLU_BF16 && bias != nullptr;   // wave-uniform
+    char* bias_strip = smem + 2 * kRing * kSliceBytes + 8 * kEpiSlab + wave * 512;
+    if (has_bias) {
+        int64_t m0, n0;
+        tile_origin(0, m0, n0);
+        bias_to_lds(bias, n0 + wn * 64, lane, bias_strip);
+    }
     stage_next(0);
     if (total > 1) {
         stage_next(1);
@@ -308,11 +313,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(const uint16_t* __restri
 
     bf16x8 xf[8], wf[4];
     int p = 0;
-    float4 bv[4];
+    f32x4 bv[4];
     for (int i = 0; i < my_tiles; ++i) {
         int64_t m0, n0;
         tile_origin(i, m0, n0);
-        load_bias<EPI>(bv, bias, n0 + wn * 64, lane);
         for (int t = 0; t < nph; ++t, ++p) {
             const char* sa = smem + (p & 3) * kSliceBytes + (wm * 128) * 64 + off;
             const char* sb = smem + (kRing + (p & 3)) * kSliceBytes + (wn * 64) * 64 + off;
@@ -321,22 +325,39 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(const uint16_t* __restri
             for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 64);
 #pragma unroll
             for (int ii = 0; ii < 8; ++ii) xf[ii] = *reinterpret_cast<const bf16x8*>(sa + ii * 16 * 64);
-            if (p + 2 < total) {
-                stage_next(p + 2);
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            } else {
+            const bool more = p + 2 < total;
+            // the next tile's bias goes out with the last slice of this one (newest operation: vmcnt(5))
+            const bool pre = has_bias && t == nph - 1 && i + 1 < my_tiles;
+            if (more) stage_next(p + 2);
+            if (pre) {
+                int64_t m1, n1;
+                tile_origin(i + 1, m1, n1);
+                bias_to_lds(bias, n1 + wn * 64, lane, bias_strip + ((i + 1) & 1) * 256);
+            }
+            if (!more) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else if (pre) {
+                asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            }
+            if (t == 0) {   // this tile's bias strip has landed: it is older than the copies just issued
+                if (has_bias) {
+                    bias_from_lds(bv, bias_strip + (i & 1) * 256, lane);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
             }
             OASR_RAW_BARRIER();
             // ---- MFMA segment
             __builtin_amdgcn_s_setprio(1);
-            if (t == 0) {   // a tile's first slice starts from a constant zero: no accumulator clearing pass
-                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            if (t == 0) {   // a tile's first slice accumulates onto the bias: no clearing pass, no bias add later
 #pragma unroll
                 for (int ii = 0; ii < 8; ++ii)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[ii], zero, 0, 0, 0);
+                        acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[ii], bv[j], 0, 0, 0);
             } else {
 #pragma unroll
                 for (int ii = 0; ii < 8; ++ii)
@@ -350,7 +371,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(const uint16_t* __restri
             // (group A's epilogue + first LOAD segment already sit between the same two barriers).
             if (!(wm == 1 && t == nph - 1)) OASR_RAW_BARRIER();
         }
-        gemm_epilogue<EPI>(acc, bv, resid, C, N, alpha, m0 + wm * 128, n0 + wn * 64, lane,
+        gemm_epilogue<EPI>(acc, resid, C, N, alpha, m0 + wm * 128, n0 + wn * 64, lane,
                            smem + 2 * kRing * kSliceBytes + wave * kEpiSlab);
         if (wm == 1) OASR_RAW_BARRIER();
     }

@@ -193,6 +193,27 @@ def test_gemm_identity_asymmetric():
     assert torch.equal(c.cpu(), w.float().t().contiguous())
 
 
+@pytest.mark.parametrize("m,n,k,epi", [(4352, 4096, 32, 0), (4352, 4096, 64, 4), (2304, 8192, 96, 3)])
+def test_gemm_bias_with_several_tiles_per_work_group_and_short_k(m, n, k, epi):
+    """More tiles than work-groups and one to three K slices per tile: every tile after a work-group's
+    first takes its bias from the strip requested during the previous tile."""
+    H = _lib()
+    g = torch.Generator().manual_seed(m + k)
+    a = _bf(torch.randn((m, k), generator=g))
+    w = _bf(torch.randn((n, k), generator=g) / math.sqrt(k))
+    bias = torch.randn((n,), generator=g) * 3
+    resid = torch.randn((m, n), generator=g) if epi == 3 else None
+    ad, wd, bd = a.cuda(), w.cuda(), bias.cuda()
+    c = resid.cuda() if epi == 3 else torch.zeros((m, n), dtype=torch.bfloat16 if epi == 0 else torch.float32, device="cuda")
+    H.check(H.lib().oasr_gemm_bf16(ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), c.data_ptr() if epi == 3 else None,
+                                   c.data_ptr(), m, n, k, 0.5 if epi == 3 else 1.0, epi, _stream()))
+    torch.cuda.synchronize()
+    ref = a.double() @ w.double().t() + bias.double()
+    if epi == 3:
+        ref = resid.double() + 0.5 * ref
+    torch.testing.assert_close(c.cpu().double(), ref, atol=2e-2 if epi == 0 else 1e-4, rtol=1e-2 if epi == 0 else 1e-5)
+
+
 def test_gemm_rejects_bad_shapes():
     H = _lib()
     z = torch.zeros((256, 256), device="cuda", dtype=torch.bfloat16)
