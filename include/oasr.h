@@ -248,7 +248,8 @@ int oasr_gemm_fp8(const uint8_t* a, const uint8_t* w, const float* scale_a, cons
  * qkv bf16 [rows][3*d] (q | k | v), ctx bf16 [rows][d], d = n_heads * head_dim; head_dim 64
  * or 128; dist_emb bf16 [96][head_dim] (rows past left_max + right_max zero).  The kernel works in
  * log2 units: q must arrive multiplied by log2(e)/sqrt(head_dim) (the encoder folds that factor into
- * the q rows of wqkv/bqkv), k and v unscaled. */
+ * the q rows of wqkv/bqkv), k and v unscaled.  Rows of an utterance between its length and t_pad are
+ * masked, not skipped: they must hold finite values (the encoder keeps them finite). */
 int oasr_attention_relkey(const uint16_t* qkv, const uint16_t* dist_emb, const int32_t* lengths,
                           uint16_t* ctx, int32_t batch, int64_t t_pad, int32_t n_heads,
                           int32_t head_dim, int32_t left_max, int32_t right_max, void* stream);

@@ -65,7 +65,7 @@ __device__ __forceinline__ float max32(const f32x16& a, const f32x16& b) {
 //       lanes a block of 4 keys x 16 channels, delivered as 4 keys of one channel per lane); vswz
 //       sends the four keys of a block to four different bank quarters (((r >> 1) & 1) << 2 for
 //       128-byte rows, where odd rows already start half a bank period later; (r & 3) << 2 for
-//       256-byte rows), so the reads and the 16-byte staging writes are conflict-free
+//       256-byte rows), so the reads are conflict-free
 template <int HD>
 struct AttnSmem {
     static constexpr int kWaves = HD / 16;   // 4 or 8
@@ -121,6 +121,11 @@ __global__ __launch_bounds__(HD * 4, HD == 64 ? 3 : 1) void attention_relkey_ker
         const uint16_t* qp = base + qrow * ld + 8 * hh;
 #pragma unroll
         for (int s = 0; s < kSteps; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + 16 * s);
+        // Pin the wait for these loads here.  Left to the compiler it lands at their first use inside the
+        // key loop as s_waitcnt vmcnt(3..0), where the counter also sees the copies of the next tile
+        // (issued from inline assembly, unknown to the compiler) and would wait for those every tile.
+#pragma unroll
+        for (int s = 0; s < kSteps; ++s) asm volatile("" : "+v"(qf[s]));
     }
     // ---- QE^T[c][q] = E[c] . Q[q]: 32-row blocks of the distance table ---------------------------------
     _Float16* qe = sm.qe[wave];
@@ -164,57 +169,52 @@ __global__ __launch_bounds__(HD * 4, HD == 64 ? 3 : 1) void attention_relkey_ker
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;   // bf16 1.0
 
-    // ---- staging roles ------------------------------------------------------------------------------------
-    // K and V: thread copies 16-byte chunks (key = tid / chunks-per-row (+32), chunk = tid % chunks-per-row)
-    const int srow = tid / kCpr, schunk = tid % kCpr;   // 32 rows per pass in both configurations
+    // ---- staging: global -> LDS copies without a register round trip ---------------------------------------
+    // A tile of K (or V) is 64 rows x kRowB bytes = kPieces pieces of 1 KiB; one global_load_lds moves a
+    // piece (16 bytes per lane, placed lane-linearly), so a lane's position in the piece fixes its LDS
+    // chunk and the swizzle is applied to the *source* chunk it fetches.  Wave w copies pieces w and
+    // w + kWaves of both operands: rows 32 apart, for which both swizzles agree, so the second piece only
+    // adds 32 rows to the source pointer.  Only the last tile can reach past row t_pad - 1: there the
+    // row is clamped (those keys are masked).  Masked keys get p = 0 exactly and their V rows are
+    // multiplied by it, so rows of qkv between an utterance's length and t_pad must be finite.
+    constexpr int kWaves = HD / 16;
+    constexpr int kRowsPerPiece = 1024 / kRowB;              // 8 or 4
     const int n_tiles = (len + kKTile - 1) / kKTile;
     const int last_row = t_pad - 1;
-    // adding 32 to a key changes none of the bits the swizzles look at
-    const int k_lds0 = srow * kRowB + ((schunk ^ kswz<HD>(srow)) << 4);
-    const int k_lds1 = k_lds0 + 32 * kRowB;
-    const int v_lds0 = srow * kRowB + ((schunk ^ vswz<HD>(srow)) << 4);
-    const int v_lds1 = v_lds0 + 32 * kRowB;
-
-    // named registers (not arrays: an array captured by the lambdas below ends up in scratch memory,
-    // which forces a wait right after each global load and defeats the prefetch)
-    uint4 kreg0, kreg1, vreg0, vreg1;
-    // Source pointers of this thread's two K rows and two V rows of the tile being requested; they
-    // advance by one tile per load.  Only the last tile can reach past row t_pad - 1: there the row
-    // index is clamped (the keys are masked anyway), everywhere else no address arithmetic is left.
-    const uint16_t* kp0 = base + d_model + schunk * 8 + (int64_t)srow * ld;
-    const uint16_t* vp0 = base + 2 * d_model + schunk * 8 + (int64_t)srow * ld;
+    const int prow = wave * kRowsPerPiece + lane / kCpr;     // this lane's row in the tile (first piece)
+    const int pchunk = lane % kCpr;                          // its chunk position in LDS
+    const uint16_t* kp0 = base + d_model + (pchunk ^ kswz<HD>(prow)) * 8 + (int64_t)prow * ld;
+    const uint16_t* vp0 = base + 2 * d_model + (pchunk ^ vswz<HD>(prow)) * 8 + (int64_t)prow * ld;
     const int64_t tile_step = (int64_t)kKTile * ld, half_step = (int64_t)32 * ld;
-    auto load_tile = [&](int kt) {
+    // The copy is written as inline assembly: through the builtin the compiler orders every later LDS
+    // read of the same array after all copies in flight (s_waitcnt vmcnt(0) in front of the first V read
+    // of each tile), which would make the prefetch of tile kt+1 wait in the middle of tile kt.  The
+    // ordering that matters is explicit here: vmcnt(0) and a barrier at the end of every tile.
+    typedef __attribute__((address_space(3))) char lds_char;
+    auto dma16 = [&](const uint16_t* src, char* dst) {   // dst: wave-uniform LDS address of a 1 KiB piece
+        const uint32_t lds_off = (uint32_t)(uintptr_t)(lds_char*)dst;
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                     :: "v"(src), "s"(lds_off) : "memory");   // M0 has no other user in this kernel
+    };
+    auto stage_tile = [&](int buf, int kt) {   // tiles are staged in order: the pointers advance by one tile
+        char* kdst = sm.k[buf] + wave * 1024;
+        char* vdst = sm.v[buf] + wave * 1024;
         if ((kt + 1) * kKTile <= t_pad) {
-            kreg0 = *reinterpret_cast<const uint4*>(kp0);
-            kreg1 = *reinterpret_cast<const uint4*>(kp0 + half_step);
-            vreg0 = *reinterpret_cast<const uint4*>(vp0);
-            vreg1 = *reinterpret_cast<const uint4*>(vp0 + half_step);
+            dma16(kp0, kdst);
+            dma16(kp0 + half_step, kdst + kWaves * 1024);
+            dma16(vp0, vdst);
+            dma16(vp0 + half_step, vdst + kWaves * 1024);
         } else {
             const int k0 = kt * kKTile;
-            const int64_t back0 = (int64_t)(k0 + srow - min(k0 + srow, last_row)) * ld;
-            const int64_t back1 = (int64_t)(k0 + 32 + srow - min(k0 + 32 + srow, last_row)) * ld;
-            kreg0 = *reinterpret_cast<const uint4*>(kp0 - back0);
-            kreg1 = *reinterpret_cast<const uint4*>(kp0 + half_step - back1);
-            vreg0 = *reinterpret_cast<const uint4*>(vp0 - back0);
-            vreg1 = *reinterpret_cast<const uint4*>(vp0 + half_step - back1);
+            const int64_t back0 = (int64_t)(k0 + prow - min(k0 + prow, last_row)) * ld;
+            const int64_t back1 = (int64_t)(k0 + 32 + prow - min(k0 + 32 + prow, last_row)) * ld;
+            dma16(kp0 - back0, kdst);
+            dma16(kp0 + half_step - back1, kdst + kWaves * 1024);
+            dma16(vp0 - back0, vdst);
+            dma16(vp0 + half_step - back1, vdst + kWaves * 1024);
         }
         kp0 += tile_step;
         vp0 += tile_step;
-    };
-    // `kt` = the tile held in the prefetch registers.  Masked keys (only in the last tile) must not
-    // inject non-finite values into P.V: their V rows are zeroed here, after the loads have landed
-    // (doing it where the loads are issued would wait for them on the spot).
-    auto store_tile = [&](int buf, int kt) {
-        if ((kt + 1) * kKTile > len) {
-            const int key = kt * kKTile + srow;
-            if (key >= len) vreg0 = make_uint4(0, 0, 0, 0);
-            if (key + 32 >= len) vreg1 = make_uint4(0, 0, 0, 0);
-        }
-        *reinterpret_cast<uint4*>(sm.k[buf] + k_lds0) = kreg0;
-        *reinterpret_cast<uint4*>(sm.k[buf] + k_lds1) = kreg1;
-        *reinterpret_cast<uint4*>(sm.v[buf] + v_lds0) = vreg0;
-        *reinterpret_cast<uint4*>(sm.v[buf] + v_lds1) = vreg1;
     };
 
     // K fragment addresses: lane (r, hh) reads key r (+32), logical chunk 2 s + hh
@@ -235,9 +235,8 @@ __global__ __launch_bounds__(HD * 4, HD == 64 ? 3 : 1) void attention_relkey_ker
         v_frag[db] = key * kRowB + ((((cbyte >> 4) ^ vswz<HD>(key)) << 4) | (cbyte & 15));
     }
 
-    load_tile(0);
-    store_tile(0, 0);
-    if (n_tiles > 1) load_tile(1);
+    stage_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     // One key tile.  FAR: every (query, key) distance of this wave's rows lies outside the clamp
@@ -249,11 +248,8 @@ __global__ __launch_bounds__(HD * 4, HD == 64 ? 3 : 1) void attention_relkey_ker
     auto process_tile = [&](auto kind_c, int kt) {
         constexpr int KIND = decltype(kind_c)::value;
         const int buf = kt & 1;
-        // stage tile kt+1 (already in registers) into the other buffer, then request tile kt+2
-        if (kt + 1 < n_tiles) {
-            store_tile(buf ^ 1, kt + 1);
-            if (kt + 2 < n_tiles) load_tile(kt + 2);
-        }
+        // request tile kt+1 into the other buffer (free since the barrier that ended tile kt-1)
+        if (kt + 1 < n_tiles) stage_tile(buf ^ 1, kt + 1);
         if (wave_active) {
             const int k0 = kt * kKTile;
             const char* kbuf = sm.k[buf];
@@ -270,12 +266,23 @@ __global__ __launch_bounds__(HD * 4, HD == 64 ? 3 : 1) void attention_relkey_ker
                     s1[e] = 0.f;
                 }
             }
+            // K fragments of four k-steps are requested together, so the MFMAs wait for the LDS once per
+            // group instead of once per pair
 #pragma unroll
-            for (int s = 0; s < kSteps; ++s) {
-                const bf16x8 ka = *reinterpret_cast<const bf16x8*>(kbuf + k_frag[s]);
-                const bf16x8 kb = *reinterpret_cast<const bf16x8*>(kbuf + 32 * kRowB + k_frag[s]);
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb, qf[s], s1, 0, 0, 0);
+            for (int s4 = 0; s4 < kSteps; s4 += 4) {
+                bf16x8 ka[4], kb[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ka[j] = *reinterpret_cast<const bf16x8*>(kbuf + k_frag[s4 + j]);
+                    kb[j] = *reinterpret_cast<const bf16x8*>(kbuf + 32 * kRowB + k_frag[s4 + j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[j], qf[s4 + j], s0, 0, 0, 0);
+                    s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[j], qf[s4 + j], s1, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // the 8 LDS reads first ...
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // ... then the 8 MFMAs
             }
             if (KIND != FAR) {
                 // c = clamp(key - q, -L, R) + L = med3(dbase + krow, 0, L + R)
@@ -354,6 +361,7 @@ __global__ __launch_bounds__(HD * 4, HD == 64 ? 3 : 1) void attention_relkey_ker
                 }
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt+1 have landed
         __syncthreads();  // tile kt+1 is staged; everyone is done reading buffer kt & 1
     };
     // start value of the S^T accumulators in FAR tiles
