@@ -48,6 +48,7 @@ class HipEngine:
         self._tickets: dict = {}
         self._copy_stream = None
         self.use_graphs = use_graphs
+        self.max_buffer_sets = 6        # distinct (batch, padded length) shapes kept resident
 
     # ---- set-up ---------------------------------------------------------------------------------------
     def _create_handle(self):
@@ -88,7 +89,10 @@ class HipEngine:
         frame_cap = 2 * t_pad
         key = (batch, t_pad)
         buf = self._buffers.get(key)
+        if buf is not None:
+            self._buffers[key] = self._buffers.pop(key)          # most recently used last
         if buf is None:
+            self._evict_buffers(self.max_buffer_sets - 1)
             dev, g = self.device, self.geometry
             rows = int(_hip.lib().oasr_encoder_rows(batch, t_pad))
             slots = int(_hip.lib().oasr_logmel_stats_slots(frame_cap))
@@ -111,6 +115,19 @@ class HipEngine:
             }
             self._buffers[key] = buf
         return buf
+
+    def _evict_buffers(self, keep: int) -> None:
+        """Drop the least recently used buffer sets beyond `keep`, together with everything that holds
+        raw pointers into them (captured graphs) or was sized for them (slots): a service that sees many
+        distinct (batch, length) shapes would otherwise keep ~1 GB per shape for ever."""
+        while len(self._buffers) > max(keep, 0):
+            torch.cuda.synchronize(self.device)                  # nothing in flight may still use them
+            (b, t_pad), _ = next(iter(self._buffers.items()))
+            del self._buffers[(b, t_pad)]
+            same = lambda bb, n: bb == b and pad_frames(_hip.num_frames(n) // 2) == t_pad
+            self._graphs = {k: v for k, v in self._graphs.items() if not same(k[2][0], k[2][1])}
+            self._tickets = {k: v for k, v in self._tickets.items() if not same(k[0], k[1])}
+            self._pinned = {k: v for k, v in self._pinned.items() if not same(k[0], k[1])}
 
     # ---- stages ---------------------------------------------------------------------------------------
     def features(self, pcm: torch.Tensor, n_valid: torch.Tensor, buf=None):

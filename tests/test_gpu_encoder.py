@@ -106,3 +106,25 @@ def test_graph_replay_equals_eager():
         torch.cuda.synchronize()
         for i, n in enumerate(lens):      # same kernels, same order: valid rows are bit-identical
             assert torch.equal(h_eager[i, :n], h_graph[i, :n])
+
+
+def test_buffer_sets_are_evicted_and_rebuilt():
+    """With room for two shapes only, a third shape drops the oldest buffer set with its graphs; coming
+    back to it rebuilds everything and gives the same states bit for bit."""
+    from omnilingual_asr.engine_hip import HipEngine
+    from tests.test_gpu_ops import synth_pcm
+
+    eng = HipEngine("GTINY", seed=1)
+    eng.max_buffer_sets = 2
+    shapes = [(2, 48000), (1, 20000), (3, 33000), (2, 48000), (1, 90000), (2, 48000)]
+    first = {}
+    for b, n in shapes:
+        pcm = synth_pcm(b, n, seed=b * 7 + n % 13).numpy()
+        hidden, lens = eng.encode_batch(pcm, [n] * b)
+        got = [hidden[i, : lens[i]].clone() for i in range(b)]
+        assert len(eng._buffers) <= 2
+        if (b, n) in first:
+            for x, y in zip(got, first[(b, n)]):
+                assert torch.equal(x, y)
+        first[(b, n)] = got
+    assert all(k[2][0] in (1, 2) for k in eng._graphs)      # the 3-row shape's graph went with its buffers
