@@ -277,6 +277,14 @@ class HipEngine:
             self._pinned[(b, n4)] = slot
         return slot
 
+    @staticmethod
+    def bucket_samples(n: int) -> int:
+        """The largest sample count that pads to the same number of encoder frames as `n`: batches
+        assembled at this width share buffers, slots and captured graphs across nearby lengths (at most
+        one shape per 32 encoder frames instead of one per distinct sample count)."""
+        t_pad = pad_frames(_hip.num_frames(max(int(n), 400)) // 2)
+        return 160 * (2 * t_pad - 1) + 400 + 156     # + 156: still 2 * t_pad frames, and a multiple of 4
+
     def host_batch(self, b: int, n: int) -> np.ndarray:
         """A page-locked [b, round_up(n, 4)] float32 array to assemble a batch in; handing it (whole) to
         `encode_batch` / `transcribe_batch` skips the staging copy.  Contents persist between calls."""

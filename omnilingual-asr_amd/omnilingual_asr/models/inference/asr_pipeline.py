@@ -315,6 +315,8 @@ class GeminiASRPipeline:
             for k, lo in enumerate(range(0, n, self.batch_size)):
                 part = bounds[lo: lo + self.batch_size]
                 width = max(int(max(e - s for s, e in part)), 400)
+                if hasattr(self.engine, "bucket_samples"):     # nearby lengths share one device shape
+                    width = self.engine.bucket_samples(width)
                 n_valid = [int(e - s) for s, e in part]
                 try:
                     if pipelined:
