@@ -65,6 +65,11 @@ def test_encoder_g300_two_layers_30s():
     _run_case("G300", [480000], n_layers_cut=2)
 
 
+def test_encoder_g300_full_depth_30s():
+    """The benchmark geometry at its full depth (12 blocks) on one 30 s utterance and a short one."""
+    _run_case("G300", [480000, 123456], seed=1)
+
+
 def test_encoder_per_layer_progression():
     """Running the first k blocks must equal the oracle's k-block output for every k."""
     from omnilingual_asr.engine_hip import HipEngine
