@@ -225,6 +225,16 @@ int oasr_gemm_bf16(const uint16_t* a, const uint16_t* w, const float* bias, cons
                    void* c, int64_t m, int64_t n, int64_t k, float alpha, int32_t epilogue,
                    void* stream);
 
+/* FLAC decode on the host (the reference accepts .flac uploads and forwards the bytes to its remote
+ * model: ref gemini_pipeline.py:106-118, workflows/wav2elan_web/app.py:76-77).  oasr_flac_info reads
+ * STREAMINFO (md5_16 may be NULL; a sample count missing from the header is found by decoding);
+ * oasr_flac_decode writes interleaved samples, sign-extended to int32 at the stream's bit depth.
+ * Frame header CRC-8 and frame CRC-16 are verified. */
+int oasr_flac_info(const uint8_t* data, int64_t size, int32_t* sample_rate, int32_t* channels,
+                   int32_t* bits, int64_t* samples_per_channel, uint8_t* md5_16);
+int oasr_flac_decode(const uint8_t* data, int64_t size, int32_t* out, int64_t capacity_per_channel,
+                     int64_t* written_per_channel);
+
 /* LayerNorm (optionally followed by Swish) straight to e4m3 rows + per-row scale: byte-identical to
  * oasr_layernorm(out_bf16=1) followed by oasr_quant_fp8_rows, without the intermediate bf16 matrix.
  * oasr_layernorm2_fp8 is the same for oasr_layernorm2 (x is overwritten with its first LayerNorm). */

@@ -1,0 +1,358 @@
+// FLAC stream decoder (host code): the lossless format among the upload types the reference accepts
+// (ref:src/omnilingual_asr/models/inference/gemini_pipeline.py:106-118, ref:workflows/wav2elan_web/app.py:76-77;
+// the reference forwards the file bytes to its remote model, here they are decoded locally).
+// Implements the FLAC format as published (RFC 9639): STREAMINFO, frame headers with CRC-8, the
+// CONSTANT / VERBATIM / FIXED / LPC subframes, both Rice residual codings with escape partitions, wasted
+// bits, the three stereo decorrelations, frame CRC-16.  Output: interleaved int32 samples.
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "oasr_common.h"
+
+namespace oasr {
+namespace flac {
+
+struct BitReader {
+    const uint8_t* p;
+    size_t n, pos = 0;   // byte position of the next byte to load
+    uint64_t acc = 0;
+    int bits = 0;        // valid bits in acc (MSB-aligned use: top `bits` of the low part)
+    bool bad = false;
+    BitReader(const uint8_t* d, size_t len) : p(d), n(len) {}
+    void fill() {
+        while (bits <= 56 && pos < n) {
+            acc = (acc << 8) | p[pos++];
+            bits += 8;
+        }
+    }
+    uint32_t get(int k) {   // 0 <= k <= 32
+        if (k == 0) return 0;
+        fill();
+        if (bits < k) {
+            bad = true;
+            return 0;
+        }
+        const uint32_t v = (uint32_t)((acc >> (bits - k)) & ((k == 32) ? 0xFFFFFFFFull : ((1ull << k) - 1)));
+        bits -= k;
+        return v;
+    }
+    int64_t get_signed(int k) {   // 1 <= k <= 33
+        if (k <= 32) {
+            const uint32_t v = get(k);
+            return (int64_t)((uint64_t)v << (64 - k)) >> (64 - k);
+        }
+        const uint64_t hi = get(k - 32);
+        const uint64_t v = (hi << 32) | get(32);
+        return (int64_t)(v << (64 - k)) >> (64 - k);
+    }
+    uint32_t unary() {   // number of 0 bits before the next 1 bit
+        uint32_t q = 0;
+        for (;;) {
+            fill();
+            if (bits == 0) {
+                bad = true;
+                return 0;
+            }
+            const uint64_t window = acc << (64 - bits);   // valid bits at the top
+            if (window == 0) {
+                q += bits;
+                bits = 0;
+                continue;
+            }
+            const int z = __builtin_clzll(window);
+            q += z;
+            bits -= z + 1;
+            return q;
+        }
+    }
+    void align() { bits -= bits & 7; }
+    size_t byte_pos() const { return pos - bits / 8; }   // only meaningful when aligned
+};
+
+static uint8_t crc8(const uint8_t* d, size_t n) {
+    uint8_t c = 0;
+    for (size_t i = 0; i < n; ++i) {
+        c ^= d[i];
+        for (int b = 0; b < 8; ++b) c = (c & 0x80) ? (uint8_t)((c << 1) ^ 0x07) : (uint8_t)(c << 1);
+    }
+    return c;
+}
+
+static uint16_t crc16(const uint8_t* d, size_t n) {
+    uint16_t c = 0;
+    for (size_t i = 0; i < n; ++i) {
+        c ^= (uint16_t)(d[i] << 8);
+        for (int b = 0; b < 8; ++b) c = (c & 0x8000) ? (uint16_t)((c << 1) ^ 0x8005) : (uint16_t)(c << 1);
+    }
+    return c;
+}
+
+struct StreamInfo {
+    int rate = 0, channels = 0, bits = 0, min_block = 0, max_block = 0;
+    int64_t total = 0;
+    uint8_t md5[16] = {0};
+    size_t audio_start = 0;
+};
+
+static int parse_header(const uint8_t* d, size_t n, StreamInfo& si) {
+    size_t pos = 0;
+    if (n >= 10 && !memcmp(d, "ID3", 3))   // a tag some writers put in front
+        pos = 10 + (((size_t)d[6] & 0x7F) << 21 | ((size_t)d[7] & 0x7F) << 14 | ((size_t)d[8] & 0x7F) << 7 | ((size_t)d[9] & 0x7F));
+    if (pos + 4 > n || memcmp(d + pos, "fLaC", 4)) {
+        set_error("flac: no fLaC stream marker");
+        return OASR_EINVAL;
+    }
+    pos += 4;
+    bool seen = false;
+    for (;;) {
+        if (pos + 4 > n) {
+            set_error("flac: truncated metadata");
+            return OASR_EINVAL;
+        }
+        const int last = d[pos] >> 7, type = d[pos] & 0x7F;
+        const size_t len = ((size_t)d[pos + 1] << 16) | ((size_t)d[pos + 2] << 8) | d[pos + 3];
+        pos += 4;
+        if (pos + len > n) {
+            set_error("flac: truncated metadata block");
+            return OASR_EINVAL;
+        }
+        if (type == 0) {
+            if (len < 34) {
+                set_error("flac: short STREAMINFO");
+                return OASR_EINVAL;
+            }
+            const uint8_t* b = d + pos;
+            si.min_block = (b[0] << 8) | b[1];
+            si.max_block = (b[2] << 8) | b[3];
+            uint64_t x = 0;
+            for (int i = 10; i < 18; ++i) x = (x << 8) | b[i];
+            si.rate = (int)(x >> 44);
+            si.channels = (int)((x >> 41) & 7) + 1;
+            si.bits = (int)((x >> 36) & 31) + 1;
+            si.total = (int64_t)(x & ((1ull << 36) - 1));
+            memcpy(si.md5, b + 18, 16);
+            seen = true;
+        }
+        pos += len;
+        if (last) break;
+    }
+    if (!seen || si.rate <= 0 || si.bits < 4 || si.bits > 32) {
+        set_error("flac: missing or invalid STREAMINFO");
+        return OASR_EINVAL;
+    }
+    si.audio_start = pos;
+    return OASR_OK;
+}
+
+static bool read_residual(BitReader& br, int64_t* out, int blocksize, int pred_order) {
+    const int method = (int)br.get(2);
+    if (method > 1) return false;
+    const int pbits = method == 0 ? 4 : 5, esc = method == 0 ? 15 : 31;
+    const int porder = (int)br.get(4);
+    const int parts = 1 << porder;
+    if ((blocksize >> porder) << porder != blocksize && porder > 0) return false;
+    int idx = 0;
+    for (int pt = 0; pt < parts; ++pt) {
+        int count = (blocksize >> porder) - (pt == 0 ? pred_order : 0);
+        if (porder == 0) count = blocksize - pred_order;
+        if (count < 0) return false;
+        const int param = (int)br.get(pbits);
+        if (param == esc) {
+            const int nb = (int)br.get(5);
+            for (int i = 0; i < count; ++i) out[idx++] = nb ? br.get_signed(nb) : 0;
+        } else {
+            for (int i = 0; i < count; ++i) {
+                const uint32_t q = br.unary();
+                const uint64_t u = ((uint64_t)q << param) | br.get(param);
+                out[idx++] = (int64_t)(u >> 1) ^ -(int64_t)(u & 1);
+            }
+        }
+        if (br.bad) return false;
+    }
+    return idx == blocksize - pred_order;
+}
+
+static bool read_subframe(BitReader& br, int64_t* s, int blocksize, int bps) {
+    if (br.get(1)) return false;
+    const int type = (int)br.get(6);
+    int wasted = 0;
+    if (br.get(1)) wasted = (int)br.unary() + 1;
+    bps -= wasted;
+    if (bps < 1 || br.bad) return false;
+    if (type == 0) {
+        const int64_t v = br.get_signed(bps);
+        for (int i = 0; i < blocksize; ++i) s[i] = v;
+    } else if (type == 1) {
+        for (int i = 0; i < blocksize; ++i) s[i] = br.get_signed(bps);
+    } else if (type >= 8 && type <= 12) {
+        const int order = type - 8;
+        if (order > blocksize) return false;
+        for (int i = 0; i < order; ++i) s[i] = br.get_signed(bps);
+        if (!read_residual(br, s + order, blocksize, order)) return false;
+        for (int i = order; i < blocksize; ++i) {
+            int64_t pred = 0;
+            switch (order) {
+                case 1: pred = s[i - 1]; break;
+                case 2: pred = 2 * s[i - 1] - s[i - 2]; break;
+                case 3: pred = 3 * s[i - 1] - 3 * s[i - 2] + s[i - 3]; break;
+                case 4: pred = 4 * s[i - 1] - 6 * s[i - 2] + 4 * s[i - 3] - s[i - 4]; break;
+                default: break;
+            }
+            s[i] += pred;
+        }
+    } else if (type >= 32) {
+        const int order = (type & 31) + 1;
+        if (order > blocksize) return false;
+        for (int i = 0; i < order; ++i) s[i] = br.get_signed(bps);
+        const int prec = (int)br.get(4) + 1;
+        if (prec == 16) return false;
+        const int shift = (int)br.get_signed(5);
+        if (shift < 0) return false;
+        int64_t coef[32];
+        for (int j = 0; j < order; ++j) coef[j] = br.get_signed(prec);
+        if (!read_residual(br, s + order, blocksize, order)) return false;
+        for (int i = order; i < blocksize; ++i) {
+            int64_t acc = 0;
+            for (int j = 0; j < order; ++j) acc += coef[j] * s[i - 1 - j];
+            s[i] += acc >> shift;
+        }
+    } else {
+        return false;   // reserved subframe type
+    }
+    if (wasted)
+        for (int i = 0; i < blocksize; ++i) s[i] = (int64_t)((uint64_t)s[i] << wasted);
+    return !br.bad;
+}
+
+// Decodes every frame; returns samples per channel written (<= capacity), or a negative status.
+static int64_t decode(const uint8_t* d, size_t n, const StreamInfo& si, int32_t* out, int64_t capacity) {
+    static const int kBlock[16] = {0, 192, 576, 1152, 2304, 4608, -8, -16, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768};
+    static const int kBits[8] = {0, 8, 12, -1, 16, 20, 24, 32};
+    size_t pos = si.audio_start;
+    int64_t done = 0;
+    std::vector<int64_t> ch[8];
+    while (pos + 2 <= n) {
+        if (!(d[pos] == 0xFF && (d[pos + 1] & 0xFE) == 0xF8)) {
+            if (si.total && done >= si.total) break;   // trailing bytes after the last frame
+            set_error("flac: lost frame sync at byte %zu", pos);
+            return OASR_EINVAL;
+        }
+        BitReader br(d + pos, n - pos);
+        br.get(16);
+        const int bs_code = (int)br.get(4), sr_code = (int)br.get(4);
+        const int ch_code = (int)br.get(4), bits_code = (int)br.get(3);
+        if (br.get(1) || bs_code == 0 || sr_code == 15 || ch_code > 10 || kBits[bits_code] < 0) {
+            set_error("flac: reserved field in a frame header at byte %zu", pos);
+            return OASR_EINVAL;
+        }
+        {   // frame or sample number, "UTF-8" coded, up to 36 bits: only skipped
+            const uint32_t b0 = br.get(8);
+            int extra = 0;
+            if (b0 >= 0xFE) extra = 6;
+            else if (b0 >= 0xFC) extra = 5;
+            else if (b0 >= 0xF8) extra = 4;
+            else if (b0 >= 0xF0) extra = 3;
+            else if (b0 >= 0xE0) extra = 2;
+            else if (b0 >= 0xC0) extra = 1;
+            for (int i = 0; i < extra; ++i) br.get(8);
+        }
+        int blocksize = kBlock[bs_code];
+        if (blocksize == -8) blocksize = (int)br.get(8) + 1;
+        else if (blocksize == -16) blocksize = (int)br.get(16) + 1;
+        if (sr_code == 12) br.get(8);
+        else if (sr_code == 13 || sr_code == 14) br.get(16);
+        const size_t hdr_len = br.byte_pos();
+        const uint32_t want8 = br.get(8);
+        if (br.bad || crc8(d + pos, hdr_len) != want8) {
+            set_error("flac: frame header CRC mismatch at byte %zu", pos);
+            return OASR_EINVAL;
+        }
+        const int bps = kBits[bits_code] ? kBits[bits_code] : si.bits;
+        const int nch = ch_code < 8 ? ch_code + 1 : 2;
+        if (nch != si.channels) {
+            set_error("flac: channel count changes inside the stream");
+            return OASR_EINVAL;
+        }
+        for (int c = 0; c < nch; ++c) {
+            ch[c].resize(blocksize);
+            const int side = (ch_code == 8 && c == 1) || (ch_code == 9 && c == 0) || (ch_code == 10 && c == 1);
+            if (!read_subframe(br, ch[c].data(), blocksize, bps + side)) {
+                set_error("flac: malformed subframe in the frame at byte %zu", pos);
+                return OASR_EINVAL;
+            }
+        }
+        br.align();
+        const size_t body_len = br.byte_pos();
+        const uint32_t want16 = br.get(16);
+        if (br.bad || crc16(d + pos, body_len) != want16) {
+            set_error("flac: frame CRC mismatch at byte %zu", pos);
+            return OASR_EINVAL;
+        }
+        if (ch_code == 8) {
+            for (int i = 0; i < blocksize; ++i) ch[1][i] = ch[0][i] - ch[1][i];
+        } else if (ch_code == 9) {
+            for (int i = 0; i < blocksize; ++i) ch[0][i] = ch[1][i] + ch[0][i];
+        } else if (ch_code == 10) {
+            for (int i = 0; i < blocksize; ++i) {
+                const int64_t side = ch[1][i], mid = ch[0][i] * 2 + (side & 1);
+                ch[0][i] = (mid + side) >> 1;
+                ch[1][i] = (mid - side) >> 1;
+            }
+        }
+        int64_t take = blocksize;
+        if (si.total && done + take > si.total) take = si.total - done;
+        if (out) {
+            if (done + take > capacity) {
+                set_error("flac: output holds %lld samples per channel, stream has more", (long long)capacity);
+                return OASR_ECAPACITY;
+            }
+            for (int64_t i = 0; i < take; ++i)
+                for (int c = 0; c < nch; ++c) out[(done + i) * nch + c] = (int32_t)ch[c][i];
+        }
+        done += take;
+        pos += br.byte_pos();
+    }
+    return done;
+}
+
+}  // namespace flac
+}  // namespace oasr
+
+using namespace oasr;
+
+extern "C" {
+
+int oasr_flac_info(const uint8_t* data, int64_t size, int32_t* sample_rate, int32_t* channels, int32_t* bits,
+                   int64_t* samples_per_channel, uint8_t* md5_16) {
+    OASR_REQUIRE(data && size > 0 && sample_rate && channels && bits && samples_per_channel, "flac_info: null pointer");
+    flac::StreamInfo si;
+    const int rc = flac::parse_header(data, (size_t)size, si);
+    if (rc != OASR_OK) return rc;
+    if (si.total == 0) {   // unknown in the header (streamed encoders): count by decoding
+        const int64_t n = flac::decode(data, (size_t)size, si, nullptr, 0);
+        if (n < 0) return (int)n;
+        si.total = n;
+    }
+    *sample_rate = si.rate;
+    *channels = si.channels;
+    *bits = si.bits;
+    *samples_per_channel = si.total;
+    if (md5_16) memcpy(md5_16, si.md5, 16);
+    return OASR_OK;
+}
+
+int oasr_flac_decode(const uint8_t* data, int64_t size, int32_t* out, int64_t capacity_per_channel,
+                     int64_t* written_per_channel) {
+    OASR_REQUIRE(data && size > 0 && out && written_per_channel, "flac_decode: null pointer");
+    flac::StreamInfo si;
+    const int rc = flac::parse_header(data, (size_t)size, si);
+    if (rc != OASR_OK) return rc;
+    const int64_t n = flac::decode(data, (size_t)size, si, out, capacity_per_channel);
+    if (n < 0) return (int)n;
+    *written_per_channel = n;
+    return OASR_OK;
+}
+
+}  // extern "C"

@@ -94,6 +94,8 @@ _SIGNATURES = {
     "oasr_attention_relkey": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "oasr_dwconv_causal": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp]),
     "oasr_dwconv_ln_swish": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_f32, c_vp]),
+    "oasr_flac_info": (c_i32, [c_vp, c_i64, C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_i64), c_vp]),
+    "oasr_flac_decode": (c_i32, [c_vp, c_i64, c_vp, c_i64, C.POINTER(c_i64)]),
     "oasr_resample_length": (c_i64, [c_i64, c_i32, c_i32]),
     "oasr_resample_poly": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp]),
     "oasr_cast_bf16": (c_i32, [c_vp, c_vp, c_i64, c_vp]),

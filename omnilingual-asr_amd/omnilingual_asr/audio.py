@@ -1,9 +1,12 @@
-"""Audio ingest: RIFF/WAVE decode, down-mix and polyphase resampling to 16 kHz mono float32.
+"""Audio ingest: WAV, AIFF/AIFF-C and FLAC decode, down-mix and polyphase resampling to 16 kHz mono
+float32.
 
 The reference hands the encoded file to its remote model and uses ffprobe/ffmpeg only for duration
 and slicing (ref:src/omnilingual_asr/models/inference/gemini_pipeline.py:222-310).  Here the host
-decodes PCM itself.  Compressed formats the reference lists (:106-118: mp3, aac, ogg, flac, m4a)
-need a decoder this package does not contain and raise `UnsupportedAudioError`.
+decodes the audio itself: PCM containers in this module, FLAC by the native decoder in
+liboasr_hip.so (`oasr_flac_decode`).  The file type is taken from its first bytes, not its name.  The
+lossy formats the reference lists (:106-118: mp3, aac, ogg, m4a) need decoders this package does not
+contain and raise `UnsupportedAudioError`.
 """
 
 from __future__ import annotations
@@ -36,10 +39,10 @@ def read_wav(path) -> tuple[np.ndarray, int]:
     """Decode a WAV file -> (float32 [frames, channels] in [-1, 1), sample_rate).
     Supports PCM 8/16/24/32-bit and IEEE float 32/64 (also via WAVE_FORMAT_EXTENSIBLE)."""
     path = Path(path)
-    if path.suffix.lower() not in (".wav", ".wave", ""):
-        raise UnsupportedAudioError(
-            f"cannot decode '{path.suffix}' audio: only RIFF/WAVE input is supported")
     data = path.read_bytes()
+    if data[:4] != b"RIFF":
+        raise UnsupportedAudioError(
+            f"cannot decode '{path.suffix}' audio: WAV, AIFF and FLAC input is supported")
     fmt = payload = None
     for cid, body in _riff_chunks(data):
         if cid == b"fmt ":
@@ -98,6 +101,32 @@ def wav_duration(path) -> float:
     raise UnsupportedAudioError("WAV header incomplete")
 
 
+def audio_duration(path) -> float:
+    """Duration in seconds from the header alone, for every container `read_audio` decodes (WAV data
+    chunk, AIFF COMM chunk, FLAC STREAMINFO); raises on anything unreadable."""
+    with open(path, "rb") as f:
+        head = f.read(1 << 16)
+    if head[:4] == b"RIFF":
+        return wav_duration(path)
+    if head[:4] == b"FORM" and head[8:12] in (b"AIFF", b"AIFC"):
+        pos = 12
+        while pos + 8 <= len(head):
+            size = struct.unpack_from(">I", head, pos + 4)[0]
+            if head[pos:pos + 4] == b"COMM" and pos + 26 <= len(head):
+                frames = struct.unpack_from(">I", head, pos + 10)[0]
+                rate = _extended80(head[pos + 16: pos + 26])
+                if rate > 0:
+                    return frames / rate
+            pos += 8 + size + (size & 1)
+        raise UnsupportedAudioError("AIFF header incomplete")
+    if head[:4] == b"fLaC" and len(head) >= 42 and head[4] & 0x7F == 0:
+        x = int.from_bytes(head[18:26], "big")
+        rate, total = x >> 44, x & ((1 << 36) - 1)
+        if rate > 0 and total > 0:
+            return total / float(rate)
+    raise UnsupportedAudioError("no duration in the header")
+
+
 def resample_filter(up: int, down: int, half_width: int = 10, beta: float = 5.0) -> np.ndarray:
     """Kaiser-windowed sinc low-pass at the up-sampled rate, cut-off at the lower Nyquist, unity
     DC gain times `up`; length 2 * half_width * max(up, down) + 1 (zero phase)."""
@@ -153,10 +182,105 @@ def resample_poly(x: np.ndarray, rate_in: int, rate_out: int = TARGET_RATE) -> n
     return y.astype(np.float32)
 
 
+def _extended80(b: bytes) -> float:
+    """IEEE 754 80-bit extended (the sample-rate field of an AIFF COMM chunk)."""
+    exp = ((b[0] & 0x7F) << 8) | b[1]
+    mant = int.from_bytes(b[2:10], "big")
+    if exp == 0 and mant == 0:
+        return 0.0
+    return (-1.0 if b[0] & 0x80 else 1.0) * mant * 2.0 ** (exp - 16383 - 63)
+
+
+def read_aiff(path) -> tuple[np.ndarray, int]:
+    """Decode AIFF / AIFF-C with uncompressed samples ('NONE', 'twos', 'sowt', 'fl32', 'fl64')
+    -> (float32 [frames, channels] in [-1, 1), sample_rate)."""
+    data = Path(path).read_bytes()
+    if len(data) < 12 or data[:4] != b"FORM" or data[8:12] not in (b"AIFF", b"AIFC"):
+        raise UnsupportedAudioError("not an AIFF file")
+    comm = ssnd = None
+    pos = 12
+    while pos + 8 <= len(data):
+        cid = data[pos:pos + 4]
+        size = struct.unpack_from(">I", data, pos + 4)[0]
+        body = data[pos + 8: pos + 8 + size]
+        if cid == b"COMM":
+            comm = body
+        elif cid == b"SSND":
+            ssnd = body
+        pos += 8 + size + (size & 1)
+    if comm is None or ssnd is None or len(comm) < 18 or len(ssnd) < 8:
+        raise UnsupportedAudioError("AIFF file lacks a COMM or SSND chunk")
+    channels, frames, bits = struct.unpack_from(">hIh", comm, 0)
+    rate = int(round(_extended80(comm[8:18])))
+    kind = comm[18:22] if data[8:12] == b"AIFC" and len(comm) >= 22 else b"NONE"
+    if channels < 1 or rate <= 0:
+        raise UnsupportedAudioError("AIFF header declares no channels or no sample rate")
+    offset = struct.unpack_from(">I", ssnd, 0)[0]
+    raw = ssnd[8 + offset:]
+    width = (bits + 7) // 8
+    if kind in (b"fl32", b"FL32"):
+        x = np.frombuffer(raw[: len(raw) // 4 * 4], dtype=">f4").astype(np.float32)
+    elif kind in (b"fl64", b"FL64"):
+        x = np.frombuffer(raw[: len(raw) // 8 * 8], dtype=">f8").astype(np.float32)
+    elif kind in (b"NONE", b"twos", b"sowt"):
+        order = "<" if kind == b"sowt" else ">"
+        n = len(raw) // width
+        if width == 1:
+            v = np.frombuffer(raw, dtype=np.int8).astype(np.int32)
+        elif width == 2:
+            v = np.frombuffer(raw[: n * 2], dtype=order + "i2").astype(np.int32)
+        elif width == 3:
+            b = np.frombuffer(raw[: n * 3], dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+            v = (b[:, 0] << 16 | b[:, 1] << 8 | b[:, 2]) if order == ">" else (b[:, 2] << 16 | b[:, 1] << 8 | b[:, 0])
+            v = (v ^ 0x800000) - 0x800000
+        elif width == 4:
+            v = np.frombuffer(raw[: n * 4], dtype=order + "i4").astype(np.int64)
+        else:
+            raise UnsupportedAudioError(f"unsupported AIFF sample width {bits}")
+        x = (v / float(1 << (8 * width - 1))).astype(np.float32)
+    else:
+        raise UnsupportedAudioError(f"compressed AIFF-C ({kind.decode('latin-1')}) is not supported")
+    n = min(x.shape[0] // channels, frames) if frames else x.shape[0] // channels
+    return x[: n * channels].reshape(n, channels), rate
+
+
+def read_flac(path) -> tuple[np.ndarray, int]:
+    """Decode a FLAC file with the native decoder -> (float32 [frames, channels] in [-1, 1), rate)."""
+    import ctypes as C
+
+    from . import _hip
+    data = Path(path).read_bytes()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    rate, channels, bits, total = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+    L = _hip.lib()
+    _hip.check(L.oasr_flac_info(buf.ctypes.data, buf.size, C.byref(rate), C.byref(channels), C.byref(bits),
+                                C.byref(total), None), "oasr_flac_info")
+    out = np.empty((max(total.value, 1), channels.value), dtype=np.int32)
+    written = C.c_int64()
+    _hip.check(L.oasr_flac_decode(buf.ctypes.data, buf.size, out.ctypes.data, out.shape[0], C.byref(written)),
+               "oasr_flac_decode")
+    x = out[: written.value].astype(np.float32) * np.float32(1.0 / (1 << (bits.value - 1)))
+    return x, int(rate.value)
+
+
+def read_audio(path) -> tuple[np.ndarray, int]:
+    """Decode by content: (float32 [frames, channels], sample_rate)."""
+    with open(path, "rb") as f:
+        head = f.read(12)
+    if head[:4] == b"RIFF":
+        return read_wav(path)
+    if head[:4] == b"FORM":
+        return read_aiff(path)
+    if head[:4] == b"fLaC" or head[:3] == b"ID3" and Path(path).suffix.lower() == ".flac":
+        return read_flac(path)
+    raise UnsupportedAudioError(
+        f"cannot decode '{Path(path).suffix}' audio: WAV, AIFF and FLAC input is supported")
+
+
 def load_audio_16k(path, resampler=None) -> np.ndarray:
     """File -> mono float32 at 16 kHz (channels averaged).  `resampler(mono, rate) -> float32 array`
     replaces the host polyphase filter when given (the device engine passes its own)."""
-    x, rate = read_wav(path)
+    x, rate = read_audio(path)
     mono = x.mean(axis=1, dtype=np.float64) if x.shape[1] > 1 else x[:, 0]
     if resampler is not None and rate != TARGET_RATE:
         return np.asarray(resampler(np.asarray(mono, dtype=np.float32), rate), dtype=np.float32)

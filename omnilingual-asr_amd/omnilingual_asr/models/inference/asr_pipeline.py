@@ -102,7 +102,7 @@ def get_audio_duration(audio_path: Path) -> float:
     """Duration in seconds from the file header; 0.0 on any failure, as the reference's ffprobe
     wrapper does (ref gemini_pipeline.py:222-240)."""
     try:
-        return float(_audio.wav_duration(audio_path))
+        return float(_audio.audio_duration(audio_path))
     except Exception:
         return 0.0
 
