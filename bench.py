@@ -290,6 +290,10 @@ def main() -> None:
 
     for _ in range(max(args.warmup, 1)):
         hidden, lengths = step(pcm, nv)
+    if world > 1:   # warm-up of the record exchange too (first use sets up the collective's channels)
+        lens_w = lengths.cpu().numpy()
+        warm = [ChunkRecord(rank * args.batch + i, 0, n, int(lens_w[i]), 0.0) for i in range(args.batch)]
+        odist.all_gather_records(odist.pack_records(warm, args.batch))
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
