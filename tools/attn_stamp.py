@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-segment cycle sums of the diagnostic attention build (tuning aid)."""
+"""Per-segment cycle sums of a diagnostic attention build with s_memtime stamps (tuning aid; the build
+is made by hand into lib/abl_astamp.so and is not part of the library)."""
 import ctypes as C, sys, os
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -7,12 +8,14 @@ os.environ["OASR_HIP_LIBRARY"] = str(ROOT / "omnilingual-asr_amd/lib/abl_astamp.
 import numpy as np
 sys.argv = [sys.argv[0], "3"]
 exec(open(ROOT / "tools/attn_one.py").read())
-buf = np.zeros(8192, dtype=np.uint64)
+buf = np.zeros(64 * 8 * 8, dtype=np.uint64)
 lib.oasr_debug_read.argtypes = [C.c_void_p, C.c_int64]
 assert lib.oasr_debug_read(buf.ctypes.data, buf.nbytes) == 0
-print("FAR tiles, ticks per tile: stage  S-mfma  max/raise  exp  PV-issue  barrier   sum")
-for wg in range(2):
+print("FAR tiles, ticks per tile:  to-S-issued  S-drain+max+raise  exp+PV-issue  vmcnt-wait  barrier    sum")
+b = buf.reshape(64, 8, 8).astype(np.float64)
+for wg in (0, 1, 2, 3, 17, 40):
     for wv in range(4):
-        b = buf[(wg * 4 + wv) * 16:(wg * 4 + wv + 1) * 16].astype(np.float64)
-        n = max(b[10], 1)
-        print(f"wg{wg} wave{wv} n={int(b[10]):3d}: " + " ".join(f"{b[q]/n:7.0f}" for q in range(6)) + f"  {sum(b[:6])/n:7.0f}   | stage split: vmwait {b[6]/n:6.0f} ds_write+drain {b[7]/n:6.0f} load-issue {(b[0]-b[6]-b[7])/n:6.0f}")
+        r = b[wg, wv]; n = max(r[5], 1)
+        print(f"wg{wg:2d} wave{wv} n={int(r[5]):3d}: " + " ".join(f"{r[q]/n:9.0f}" for q in range(5)) + f"  {r[:5].sum()/n:8.0f}")
+tot = b[:, :4, :5].sum(axis=(0, 1)); n = b[:, :4, 5].sum()
+print("mean over 64 work-groups:     " + " ".join(f"{v/n:9.0f}" for v in tot) + f"  {tot.sum()/n:8.0f}")
