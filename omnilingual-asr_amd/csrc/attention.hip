@@ -12,9 +12,9 @@
 // MFMA orientation (v_mfma_f32_32x32x16_bf16): S^T = K . Q^T, so a lane holds one query column and
 // 16 keys of it in registers — the row max is in-register plus one exchange with lane^32, and the
 // rescale factor is a per-lane scalar.  The S^T accumulator, converted to bf16, is directly the B
-// operand of O^T = V^T . P^T (summing over its row index), so P never touches LDS; the row sums come
-// from one more MFMA per k-step with an all-ones A operand (every row of its result is the column
-// sum of P^T), which moves 32 additions per lane and tile from the vector ALU to the matrix pipe.
+// operand of O^T = V^T . P^T (summing over its row index), so P never touches LDS; the row sums are
+// float32 additions of the unrounded p on the vector ALU (an all-ones MFMA per k-step was tried first:
+// it loads the matrix pipe, the busier one here, with a fifth more work and holds 16 registers).
 // Softmax bookkeeping is relative to a lazily raised running max m: the S^T accumulators start from
 // (bias - m) instead of zero in tiles where the relative-key term is one value per query, so there
 // p = exp2(accumulator) with no arithmetic in between; m moves (and O, the sums and the tile's
@@ -155,19 +155,16 @@ __global__ __launch_bounds__(HD * 4, HD == 64 ? 3 : 1) void attention_relkey_ker
     const float bias_left = wave_active ? (float)qe[0 * 32 + r] : 0.f;
     const float bias_right = wave_active ? (float)qe[(n_dist - 1) * 32 + r] : 0.f;
 
-    f32x16 o[kOut], lacc, offv;
+    f32x16 o[kOut], offv;
+    float lsum = 0.f;   // this lane's share of its query's row sum (keys of its half only)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
 #pragma unroll
         for (int db = 0; db < kOut; ++db) o[db][e] = 0.f;
-        lacc[e] = 0.f;
         offv[e] = 0.f;
     }
     float m_run = 0.f;       // running max (log2 units); set from the first tile's true max
     bool first_tile = true;  // wave-uniform
-    bf16x8 ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;   // bf16 1.0
 
     // ---- staging: global -> LDS copies without a register round trip ---------------------------------------
     // A tile of K (or V) is 64 rows x kRowB bytes = kPieces pieces of 1 KiB; one global_load_lds moves a
@@ -320,11 +317,11 @@ __global__ __launch_bounds__(HD * 4, HD == 64 ? 3 : 1) void attention_relkey_ker
                 for (int e = 0; e < 16; ++e) {
 #pragma unroll
                     for (int db = 0; db < kOut; ++db) o[db][e] *= alpha;
-                    lacc[e] *= alpha;
                     s0[e] -= delta;
                     s1[e] -= delta;
                     offv[e] -= delta;
                 }
+                lsum *= alpha;
                 first_tile = false;
             }
             // ---- p = exp2(score - m_run) -----------------------------------------------------------------------
@@ -333,7 +330,18 @@ __global__ __launch_bounds__(HD * 4, HD == 64 ? 3 : 1) void attention_relkey_ker
                 s0[e] = __builtin_amdgcn_exp2f(s0[e]);
                 s1[e] = __builtin_amdgcn_exp2f(s1[e]);
             }
-            // ---- O^T += V^T . P^T and row sums += 1 . P^T ---------------------------------------------------
+            {   // row sum on the vector ALU: four independent chains
+                float a0 = s0[0] + s1[0], a1 = s0[1] + s1[1], a2 = s0[2] + s1[2], a3 = s0[3] + s1[3];
+#pragma unroll
+                for (int e = 4; e < 16; e += 4) {
+                    a0 += s0[e] + s1[e];
+                    a1 += s0[e + 1] + s1[e + 1];
+                    a2 += s0[e + 2] + s1[e + 2];
+                    a3 += s0[e + 3] + s1[e + 3];
+                }
+                lsum += (a0 + a1) + (a2 + a3);
+            }
+            // ---- O^T += V^T . P^T ------------------------------------------------------------------------------
             // k-step (u, s2): P fragment = registers 8 s2 .. 8 s2 + 7 of S_u; its element j is key
             // 32 u + 16 s2 + 8 (j >> 2) + 4 hh + (j & 3), so V^T is read as two 8-byte pieces.
 #pragma unroll
@@ -357,7 +365,6 @@ __global__ __launch_bounds__(HD * 4, HD == 64 ? 3 : 1) void attention_relkey_ker
                         const bf16x8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
                         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
                     }
-                    lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);
                 }
             }
         }
@@ -390,7 +397,11 @@ __global__ __launch_bounds__(HD * 4, HD == 64 ? 3 : 1) void attention_relkey_ker
 
     if (!wave_active) return;
     // ---- normalise and store: lane holds ctx[q][32 db + 8 g + 4 hh + {0..3}] ---------------------------------
-    const float inv = 1.0f / lacc[0];   // every row of the ones-product is the full row sum
+    float inv;
+    {   // the other half of this query's keys was summed by lane ^ 32
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lsum), __float_as_uint(lsum), false, false);
+        inv = 1.0f / (__uint_as_float(sw[0]) + __uint_as_float(sw[1]));
+    }
     const int q = qw0 + r;
     if (q < t_pad) {
         uint16_t* op = ctx + ((int64_t)b * t_pad + q) * d_model + head * kHead + 4 * hh;
