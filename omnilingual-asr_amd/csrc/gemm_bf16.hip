@@ -113,8 +113,8 @@ __device__ __forceinline__ void bias_from_lds(f32x4 (&bv)[4], const char* strip,
 }
 
 // acc[i][j]: lane (fr = lane & 15, fq = lane >> 4) holds C[mbase + 16 i + fr][nbase + 16 j + 4 fq + 0..3].
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[8][4],
+template <int EPI, int MI = 8>
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][4],
                                               const float* resid, void* C, int64_t N, float alpha,
                                               int64_t mbase, int64_t nbase, int lane, char* slab) {
     const int fr = lane & 15, fq = lane >> 4;
@@ -122,7 +122,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[8][4],
         const int rrow = lane >> 3, rchunk = lane & 7;   // read-back role: rows rrow, rrow + 8; 16-byte chunk
         uint16_t* cbase = reinterpret_cast<uint16_t*>(C) + (mbase + rrow) * N + nbase + rchunk * 8;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 f32x4 v = acc[i][j];
@@ -144,7 +144,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[8][4],
         const int rrow = lane >> 2, rchunk = lane & 3;   // 16 rows x 64 B
         uint16_t* cbase = reinterpret_cast<uint16_t*>(C) + (mbase + rrow) * (N >> 1) + (nbase >> 1) + rchunk * 8;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int j = 0; j < 4; j += 2) {
                 const f32x4 v = acc[i][j], g = acc[i][j + 1];
@@ -174,8 +174,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[8][4],
                 for (int r2 = 0; r2 < 2; ++r2) rcur[h][r2] = *reinterpret_cast<const float4*>(resid + index_of(0, h, r2));
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (EPI == OASR_EPI_RESIDUAL_F32 && i + 1 < 8) {
+        for (int i = 0; i < MI; ++i) {
+            if (EPI == OASR_EPI_RESIDUAL_F32 && i + 1 < MI) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -383,6 +383,98 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(const uint16_t* __restri
     if (wm == 0) OASR_RAW_BARRIER();  // same barrier count in both groups
 }
 
+
+// Small-problem variant: 128 x 128 output tiles, 4 waves as 2 (m) x 2 (n), a wave owns 64 x 64.  Used
+// when the 256 x 256 tiling would leave more than half of the CUs without a tile (a single 30 s
+// utterance has 6 m-tiles).
+// Same K slices, ring, swizzle, MFMA and epilogues as the kernel above, so every output element is
+// computed by the same sequence of operations and the results are bit-identical to it.  One tile per
+// work-group and one barrier per K slice; two work-groups fit a CU (73 KiB of LDS each) and cover each
+// other's LOAD segments and epilogues.
+constexpr int kSmallTile = 128;
+constexpr int kSmallSlice = kSmallTile * BK * 2;   // 8 KiB per operand per ring slot
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_small_kernel(const uint16_t* __restrict__ A,
+                                                                 const uint16_t* __restrict__ W,
+                                                                 const float* __restrict__ bias, const float* resid,
+                                                                 void* C, int64_t N, int64_t K, float alpha,
+                                                                 int tiles_m, int n_tiles) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * kRing * kSmallSlice + 4 * kEpiSlab];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    // contiguous run of tiles per XCD (work-groups with equal blockIdx % 8 share one), m fastest: the
+    // work-groups of an XCD share few weight panels
+    int tile;
+    {
+        const int q8 = n_tiles / 8, r8 = n_tiles % 8, xcd = blockIdx.x % 8;
+        tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + blockIdx.x / 8;
+    }
+    const int64_t m0 = (int64_t)(tile % tiles_m) * kSmallTile, n0 = (int64_t)(tile / tiles_m) * kSmallTile;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int off = fr * 64 + ((fq ^ ((4 - (fr >> 2)) & 3)) << 4);
+    const int nph = (int)(K / BK);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (EPI != OASR_EPI_GLU_BF16 && bias) {
+            const float4 t = *reinterpret_cast<const float4*>(bias + n0 + wn * 64 + j * 16 + fq * 4);
+            b = (f32x4){t.x, t.y, t.z, t.w};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = b;   // the accumulators start from the bias
+    }
+
+    // staging: a slice is 8 pieces of 16 rows per operand; wave w copies pieces 2 w, 2 w + 1 of both
+    const uint32_t lane_off =
+        (uint32_t)(((lane >> 2) * K + (((lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3)) << 3)) * 2);
+    const int64_t piece_stride = 16 * K * 2;
+    const char* st_a = reinterpret_cast<const char*>(A) + (m0 + wave * 32) * K * 2;
+    const char* st_w = reinterpret_cast<const char*>(W) + (n0 + wave * 32) * K * 2;
+    auto stage_next = [&](int p) {
+        stage_slice(st_a, lane_off, piece_stride, smem + (p & 3) * kSmallSlice, wave);
+        stage_slice(st_w, lane_off, piece_stride, smem + (kRing + (p & 3)) * kSmallSlice, wave);
+        st_a += BK * 2;
+        st_w += BK * 2;
+    };
+    stage_next(0);
+    if (nph > 1) {
+        stage_next(1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    OASR_RAW_BARRIER();
+
+    bf16x8 xf[4], wf[4];
+    for (int p = 0; p < nph; ++p) {
+        const char* sa = smem + (p & 3) * kSmallSlice + (wm * 64) * 64 + off;
+        const char* sb = smem + (kRing + (p & 3)) * kSmallSlice + (wn * 64) * 64 + off;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 64);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) xf[ii] = *reinterpret_cast<const bf16x8*>(sa + ii * 16 * 64);
+        // slot (p + 2) & 3 held slice p - 2: every wave finished reading it before the barrier of slice p - 1
+        if (p + 2 < nph) {
+            stage_next(p + 2);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // own pieces of slice p + 1 have landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        OASR_RAW_BARRIER();                                    // ... and so have everyone else's
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[ii], acc[ii][j], 0, 0, 0);
+    }
+    gemm_epilogue<EPI, 4>(acc, resid, C, N, alpha, m0 + wm * 64, n0 + wn * 64, lane,
+                          smem + 2 * kRing * kSmallSlice + wave * kEpiSlab);
+}
+
 }  // namespace oasr
 
 using namespace oasr;
@@ -400,6 +492,26 @@ extern "C" int oasr_gemm_bf16(const uint16_t* a, const uint16_t* w, const float*
                  "gemm: operands must be 16-byte aligned");
     OASR_REQUIRE(epilogue != OASR_EPI_RESIDUAL_F32 || resid != nullptr, "gemm: residual epilogue without resid");
     const int tiles = (int)((m / BM) * (n / BN));
+    if (tiles < kMaxCUs / 2) {   // 256 x 256 tiles for fewer than half of the CUs: 128 x 128 tiles, same arithmetic
+        // (measured: faster below ~128 large tiles, slower at 192)
+        const int tm = (int)(m / kSmallTile), nt = tm * (int)(n / kSmallTile);
+        hipStream_t st = (hipStream_t)stream;
+#define OASR_LAUNCH_SMALL(E) \
+    hipLaunchKernelGGL((gemm_bf16_small_kernel<E>), dim3((unsigned)nt), dim3(256), 0, st, a, w, bias, resid, c, n, k, alpha, tm, nt)
+        switch (epilogue) {
+            case OASR_EPI_BIAS_BF16: OASR_LAUNCH_SMALL(OASR_EPI_BIAS_BF16); break;
+            case OASR_EPI_BIAS_SWISH_BF16: OASR_LAUNCH_SMALL(OASR_EPI_BIAS_SWISH_BF16); break;
+            case OASR_EPI_GLU_BF16: OASR_LAUNCH_SMALL(OASR_EPI_GLU_BF16); break;
+            case OASR_EPI_RESIDUAL_F32: OASR_LAUNCH_SMALL(OASR_EPI_RESIDUAL_F32); break;
+            case OASR_EPI_BIAS_F32: OASR_LAUNCH_SMALL(OASR_EPI_BIAS_F32); break;
+            default:
+                set_error("gemm: unknown epilogue %d", epilogue);
+                return OASR_EINVAL;
+        }
+#undef OASR_LAUNCH_SMALL
+        OASR_CHECK_LAUNCH("gemm (small tiles)");
+        return OASR_OK;
+    }
     // one persistent work-group per CU; the grid is a multiple of 8 so that every XCD gets the same
     // number of work-groups
     dim3 grid((unsigned)(tiles < kMaxCUs ? (tiles + 7) / 8 * 8 : kMaxCUs)), blk(512);

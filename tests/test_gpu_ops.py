@@ -214,6 +214,31 @@ def test_gemm_bias_with_several_tiles_per_work_group_and_short_k(m, n, k, epi):
     torch.testing.assert_close(c.cpu().double(), ref, atol=2e-2 if epi == 0 else 1e-4, rtol=1e-2 if epi == 0 else 1e-5)
 
 
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+def test_gemm_small_tiles_equal_large_tiles_bit_for_bit(epi):
+    """Problems with fewer than 256 tiles of 256 x 256 run on 128 x 128 tiles; both kernels perform the
+    same operations per output element, so the first rows of a large problem equal a small problem on
+    those rows exactly (this is what keeps an utterance's states independent of the batch it is in)."""
+    H = _lib()
+    g = torch.Generator().manual_seed(epi)
+    m_big, m_small, n, k = 4096, 768, 4096, 512
+    a = _bf(torch.randn((m_big, k), generator=g)).cuda()
+    w = _bf(torch.randn((n, k), generator=g) / math.sqrt(k)).cuda()
+    bias = None if epi == 2 else torch.randn((n,), generator=g).cuda()
+    n_out = n // 2 if epi == 2 else n
+    outs = []
+    for m in (m_big, m_small):
+        if epi == 3:
+            c = torch.randn((m_big, n_out), generator=torch.Generator().manual_seed(9))[:m].contiguous().cuda()
+        else:
+            c = torch.zeros((m, n_out), dtype=torch.bfloat16, device="cuda")
+        H.check(H.lib().oasr_gemm_bf16(a.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                       c.data_ptr() if epi == 3 else None, c.data_ptr(), m, n, k, 0.5, epi, _stream()))
+        outs.append(c)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][:m_small], outs[1])
+
+
 def test_gemm_rejects_bad_shapes():
     H = _lib()
     z = torch.zeros((256, 256), device="cuda", dtype=torch.bfloat16)
