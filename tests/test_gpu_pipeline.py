@@ -132,3 +132,20 @@ def test_audio_shorter_than_the_first_stacked_frame_on_hip(tmp_path, n, end):
     assert len(segs) == 1 and (segs[0].start, segs[0].end) == (0.0, end)
     if n < 720:
         assert segs[0].text == "" and segs[0].words == []
+
+
+def test_bench_long_audio_mode_runs(tmp_path):
+    """`bench.py --hours` (the auto-chunked long-audio configuration) end to end in a child process:
+    planner, shard synthesis, two-deep chunk loop, record checks, one JSON line."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--hours", "0.06", "--model", "GTINY", "--batch", "4"],
+                         capture_output=True, text=True, timeout=180, cwd=str(root))
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["config"]["chunks"] == 8 and line["n_gpus"] == 1 and line["value"] > 0      # 216 s -> 7 x 30 s + 6 s
+    assert line["unit"] == "x real time" and line["steps"] == 2
