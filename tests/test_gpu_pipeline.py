@@ -149,3 +149,24 @@ def test_bench_long_audio_mode_runs(tmp_path):
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["config"]["chunks"] == 8 and line["n_gpus"] == 1 and line["value"] > 0      # 216 s -> 7 x 30 s + 6 s
     assert line["unit"] == "x real time" and line["steps"] == 2
+
+
+def test_four_threads_share_one_pipeline(tmp_path):
+    """The reference's server runs up to four `transcribe()` calls at once on one shared instance
+    (ref:workflows/wav2elan_web/app.py:383-399): results must equal the one-at-a-time results."""
+    from concurrent.futures import ThreadPoolExecutor
+    from omnilingual_asr import Pipeline
+
+    paths = []
+    for i, (seconds, rate) in enumerate([(3.0, 16000), (41.0, 16000), (7.5, 22050), (65.2, 8000), (0.5, 16000), (33.3, 44100)]):
+        p = tmp_path / f"f{i}.wav"
+        _write_wav(p, seconds, rate=rate, seed=20 + i)
+        paths.append(str(p))
+    pipe = Pipeline(model="GTINY", seed=5, batch_size=2)
+    key = lambda segs: [(s.start, s.end, s.text, None if s.words is None else [(w.word, w.start, w.end) for w in s.words]) for s in segs]
+    want = [key(pipe.transcribe(p, word_timestamps=True)) for p in paths]
+    assert [len(w) for w in want] == [1, 2, 1, 3, 1, 2]
+    for _ in range(2):
+        with ThreadPoolExecutor(max_workers=4) as ex:
+            got = list(ex.map(lambda p: key(pipe.transcribe(p, word_timestamps=True)), paths))
+        assert got == want
