@@ -1,5 +1,9 @@
+"""Prints the measured parity figures of the benchmark geometry at full depth against the CPU oracle
+(run by hand on the GPU box: python3 tests/parity_numbers.py; not collected by pytest)."""
 import sys
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/omnilingual-asr_amd")
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "omnilingual-asr_amd"))
 import torch, numpy as np
 from omnilingual_asr.engine_hip import HipEngine
 from omnilingual_asr.weights import GEOMETRIES, init_random_weights
