@@ -103,7 +103,7 @@ int oasr_plan_chunks(int64_t total_samples, int32_t sample_rate, double chunk_se
     const double duration = (double)total / (double)sample_rate;
     int64_t step = total;  // one chunk
     if (total > 0 && duration > min_chunking_seconds) {
-        step = (int64_t)llround(chunk_seconds * (double)sample_rate);
+        step = (int64_t)nearbyint(chunk_seconds * (double)sample_rate);   // ties to even, like the oracle
         OASR_REQUIRE(step > 0, "plan_chunks: chunk_seconds too small");
     }
     const int64_t n = total == 0 ? 1 : (total + step - 1) / step;
