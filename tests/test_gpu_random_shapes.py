@@ -82,3 +82,85 @@ def test_resampler_on_random_rates():
         ref = audio.resample_poly(x, rate)
         assert y.shape == ref.shape, (rate, n)
         np.testing.assert_allclose(y, ref, rtol=0, atol=1.2e-7)
+
+
+def test_gemm_on_random_shapes_and_epilogues():
+    """Random m, n (multiples of 256) and k (multiples of 32), every epilogue, both tile sizes, against a
+    float64 product of the same bf16 operands."""
+    import math
+    from omnilingual_asr import _hip as H
+    from omnilingual_asr.weights import glu_interleave
+
+    rng = np.random.default_rng(21)
+    st = torch.cuda.current_stream().cuda_stream
+    bf = lambda t: t.to(torch.bfloat16)
+    for trial in range(14):
+        m = 256 * int(rng.integers(1, 26))
+        n = 256 * int(rng.integers(1, 20))
+        k = 32 * int(rng.integers(1, 40))
+        epi = int(rng.integers(0, 5))
+        g = torch.Generator().manual_seed(trial)
+        a = bf(torch.randn((m, k), generator=g))
+        w = bf(torch.randn((n, k), generator=g) / math.sqrt(k))
+        bias = torch.randn((n,), generator=g)
+        alpha = float(rng.choice([1.0, 0.5]))
+        acc = a.double() @ w.double().t()
+        ad, bd = a.cuda(), bias.cuda()
+        if epi == H.EPI_GLU_BF16:
+            wd = bf(glu_interleave(w.float())).cuda()
+            c = torch.full((m, n // 2), float("nan"), device="cuda", dtype=torch.bfloat16)
+            args = (ad.data_ptr(), wd.data_ptr(), None, None, c.data_ptr())
+            ref = acc[:, : n // 2] * torch.sigmoid(acc[:, n // 2:])
+        elif epi == H.EPI_RESIDUAL_F32:
+            wd = w.cuda()
+            resid = torch.randn((m, n), generator=g)
+            c = resid.cuda().clone()
+            args = (ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), c.data_ptr(), c.data_ptr())
+            ref = resid.double() + alpha * (acc + bias.double())
+        else:
+            wd = w.cuda()
+            c = torch.full((m, n), float("nan"), device="cuda", dtype=torch.float32 if epi == H.EPI_BIAS_F32 else torch.bfloat16)
+            args = (ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), None, c.data_ptr())
+            ref = acc + bias.double()
+            if epi == H.EPI_BIAS_SWISH_BF16:
+                ref = ref * torch.sigmoid(ref)
+        H.check(H.lib().oasr_gemm_bf16(*args, m, n, k, alpha if epi == H.EPI_RESIDUAL_F32 else 1.0, epi, st))
+        torch.cuda.synchronize()
+        tol = 2e-4 if c.dtype == torch.float32 else 2.5e-2
+        torch.testing.assert_close(c.float().cpu().double(), ref, atol=tol, rtol=tol, msg=lambda s: f"{(trial, m, n, k, epi)}: {s}")
+
+
+def test_attention_on_random_shapes():
+    """Random batch, heads, head size, padded length and ragged lengths (down to one key)."""
+    from omnilingual_asr import _hip as H
+    from tests.test_gpu_ops import _attention_ref, _prescale_q
+
+    rng = np.random.default_rng(31)
+    st = torch.cuda.current_stream().cuda_stream
+    for trial in range(10):
+        head = int(rng.choice([64, 128]))
+        heads = int(rng.integers(1, 5))
+        batch = int(rng.integers(1, 4))
+        t_pad = 32 * int(rng.integers(1, 20))
+        lens = [int(rng.integers(1, t_pad + 1)) for _ in range(batch)]
+        d = heads * head
+        g = torch.Generator().manual_seed(200 + trial)
+        qkv, qkv_ref = _prescale_q(torch.randn((batch, t_pad, 3 * d), generator=g), d, head)
+        emb = torch.zeros((96, head))
+        emb[:73] = torch.randn((73, head), generator=g) * (8.0 / head ** 0.5)
+        emb = emb.to(torch.bfloat16)
+        lengths = torch.tensor(lens, dtype=torch.int32)
+        rows = (batch * t_pad + 255) // 256 * 256
+        qkv_d = torch.zeros((rows, 3 * d), dtype=torch.bfloat16, device="cuda")
+        qkv_d[: batch * t_pad] = qkv.reshape(-1, 3 * d).cuda()
+        ctx = torch.zeros((rows, d), dtype=torch.bfloat16, device="cuda")
+        emb_d, len_d = emb.cuda(), lengths.cuda()
+        H.check(H.lib().oasr_attention_relkey(qkv_d.data_ptr(), emb_d.data_ptr(), len_d.data_ptr(), ctx.data_ptr(),
+                                              batch, t_pad, heads, head, 64, 8, st))
+        torch.cuda.synchronize()
+        ref = _attention_ref(qkv_ref, emb.float()[:73], lengths.long(), heads, 64, 8)
+        got = ctx[: batch * t_pad].float().cpu().reshape(batch, t_pad, d).double()
+        assert torch.isfinite(got).all()
+        for i, n in enumerate(lens):
+            torch.testing.assert_close(got[i, :n], ref[i, :n], atol=3e-2, rtol=3e-2,
+                                       msg=lambda s: f"{(trial, head, heads, batch, t_pad, lens, i)}: {s}")
