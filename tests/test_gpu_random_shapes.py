@@ -164,3 +164,39 @@ def test_attention_on_random_shapes():
         for i, n in enumerate(lens):
             torch.testing.assert_close(got[i, :n], ref[i, :n], atol=3e-2, rtol=3e-2,
                                        msg=lambda s: f"{(trial, head, heads, batch, t_pad, lens, i)}: {s}")
+
+
+def test_encoder_on_random_ragged_batches():
+    """The whole device path (features + two-block encoder) on random batch sizes and lengths against
+    the float32 oracle, bf16 tolerance; lengths bit-exact."""
+    from omnilingual_asr.engine_hip import HipEngine
+    from omnilingual_asr.weights import GEOMETRIES, init_random_weights
+    from oracle import conformer as OC
+    from oracle import logmel as OL
+    from tests.test_gpu_ops import synth_pcm
+
+    g = GEOMETRIES["GTINY"]
+    w = init_random_weights(g, 7)
+    eng = HipEngine(g, weights=w)
+    og = OC.Geometry(name=g.name, d_model=g.d_model, ffn_dim=g.ffn_dim, n_heads=g.n_heads, n_layers=g.n_layers)
+    rng = np.random.default_rng(41)
+    for trial in range(5):
+        batch = int(rng.integers(1, 6))
+        n_list = [int(rng.integers(720, 90000)) for _ in range(batch)]
+        if trial == 2:
+            n_list[0] = 300                                 # one row without a single frame
+        n_max = max(n_list)
+        src = synth_pcm(batch, n_max, seed=300 + trial)
+        pcm = torch.zeros((batch, (n_max + 3) // 4 * 4))
+        for i, n in enumerate(n_list):
+            pcm[i, :n] = src[i, :n]
+        hidden, lengths = eng.encode_batch(pcm, n_list)
+        feats, lens = OL.features_batch(pcm.numpy(), n_list)
+        assert list(lengths) == list(lens), (trial, n_list)
+        ref = OC.forward(torch.from_numpy(feats), torch.from_numpy(lens), w, og)
+        got = hidden.cpu()
+        for i, n in enumerate(lens):
+            if n == 0:
+                continue
+            d = got[i, :n] - ref[i, :n]
+            assert float(d.norm() / ref[i, :n].norm()) <= 2e-2 and float(d.abs().max()) <= 0.15, (trial, i, n_list)
