@@ -292,7 +292,7 @@ def main() -> None:
         hidden, lengths = step(pcm, nv)
     if world > 1:   # warm-up of the record exchange too (first use sets up the collective's channels)
         lens_w = lengths.cpu().numpy()
-        warm = [ChunkRecord(rank * args.batch + i, 0, n, int(lens_w[i]), 0.0) for i in range(args.batch)]
+        warm = [ChunkRecord(rank * args.batch + i, 0, n, int(lens_w[i])) for i in range(args.batch)]
         odist.all_gather_records(odist.pack_records(warm, args.batch))
     sync_all()
     t0 = time.perf_counter()
@@ -300,7 +300,7 @@ def main() -> None:
         hidden, lengths = step(pcm, nv)
     # end of job: per-chunk records, exchanged by the path's single all-gather
     lens_h = lengths.cpu().numpy()
-    recs = [ChunkRecord(rank * args.batch + i, 0, n, int(lens_h[i]), 0.0) for i in range(args.batch)]
+    recs = [ChunkRecord(rank * args.batch + i, 0, n, int(lens_h[i])) for i in range(args.batch)]
     if world > 1:
         gathered = odist.all_gather_records(odist.pack_records(recs, args.batch))
         assert gathered.shape[0] == world * args.batch

@@ -116,13 +116,13 @@ int oasr_feature_norm_stack(const float* logmel, float* stats, const int32_t* n_
  * that must outlive the handle. */
 typedef struct oasr_encoder_config {
     int32_t feat_dim;     /* 160 */
-    int32_t d_model;      /* multiple of 256 */
+    int32_t d_model;      /* 512, 1024, 2048 or 4096 */
     int32_t ffn_dim;      /* multiple of 256 */
-    int32_t n_heads;      /* d_model / n_heads must be 64 */
+    int32_t n_heads;      /* d_model / n_heads must be 64 or 128 */
     int32_t n_layers;
     int32_t conv_kernel;  /* 31 */
     int32_t left_max;     /* 64 */
-    int32_t right_max;    /* 8 */
+    int32_t right_max;    /* 8;  left_max + right_max + 1 <= 80 */
     float ln_eps;
 } oasr_encoder_config;
 
@@ -288,10 +288,14 @@ int oasr_cast_bf16(const float* x, uint16_t* y, int64_t n, void* stream);
 /* Greedy CTC decode.  logits float32 [batch * t_pad][ld], columns 0..vocab-1 meaningful.  Per
  * utterance b and frame t < lengths[b]: id = argmax (lowest index on ties); a frame is kept when
  * id != blank and id differs from the previous frame's id.  tokens / frames int32 [batch][t_pad]
- * receive the kept ids and their frame indices, -1 past counts[b]. */
+ * receive the kept ids and their frame indices, -1 past counts[b].  Any t_pad (a 300 s chunk of
+ * the reference's plan, ref gemini_pipeline.py:217, is 15 008 frames).  workspace: device,
+ * oasr_ctc_workspace_bytes(batch, t_pad) bytes, 4-byte aligned — receives the per-frame winners
+ * between the two launches; contents on entry do not matter. */
+int64_t oasr_ctc_workspace_bytes(int32_t batch, int64_t t_pad);
 int oasr_ctc_greedy(const float* logits, int64_t ld, int32_t vocab, const int32_t* lengths,
                     int32_t batch, int64_t t_pad, int32_t blank, int32_t* tokens, int32_t* frames,
-                    int32_t* counts, void* stream);
+                    int32_t* counts, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Sample-rate conversion to 16 kHz on the device.  The reference sends the file as it is to its

@@ -190,8 +190,10 @@ __global__ __launch_bounds__(HD * 4, HD == 64 ? 3 : 1) void attention_relkey_ker
     typedef __attribute__((address_space(3))) char lds_char;
     auto dma16 = [&](const uint16_t* src, char* dst) {   // dst: wave-uniform LDS address of a 1 KiB piece
         const uint32_t lds_off = (uint32_t)(uintptr_t)(lds_char*)dst;
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                     :: "v"(src), "s"(lds_off) : "memory");   // M0 has no other user in this kernel
+        uint32_t saved;                       // M0 is left as it was found: the compiler reserves it
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(saved) : "v"(src), "s"(lds_off) : "memory");
     };
     auto stage_tile = [&](int buf, int kt) {   // tiles are staged in order: the pointers advance by one tile
         char* kdst = sm.k[buf] + wave * 1024;

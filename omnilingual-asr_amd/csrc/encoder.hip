@@ -67,15 +67,15 @@ int oasr_encoder_create(const oasr_encoder_config* cfg, const oasr_top_weights* 
     OASR_REQUIRE(cfg && top && out, "encoder_create: null pointer");
     OASR_REQUIRE(cfg->n_layers >= 0 && (cfg->n_layers == 0 || layers), "encoder_create: layers missing");
     OASR_REQUIRE(cfg->feat_dim == OASR_FEAT_DIM, "encoder_create: feat_dim must be %d", OASR_FEAT_DIM);
-    OASR_REQUIRE(cfg->d_model > 0 && cfg->d_model % 512 == 0 && cfg->d_model <= 4096,
-                 "encoder_create: d_model must be a multiple of 512, at most 4096");
+    OASR_REQUIRE(cfg->d_model == 512 || cfg->d_model == 1024 || cfg->d_model == 2048 || cfg->d_model == 4096,
+                 "encoder_create: d_model must be 512, 1024, 2048 or 4096 (the LayerNorm kernels' row widths)");
     OASR_REQUIRE(cfg->ffn_dim > 0 && cfg->ffn_dim % 256 == 0, "encoder_create: ffn_dim must be a multiple of 256");
     OASR_REQUIRE(cfg->n_heads > 0 && (cfg->d_model == cfg->n_heads * 64 || cfg->d_model == cfg->n_heads * 128),
                  "encoder_create: head size (d_model / n_heads) must be 64 or 128");
     OASR_REQUIRE(cfg->conv_kernel == 31 || cfg->conv_kernel == 15 || cfg->conv_kernel == 7 || cfg->conv_kernel == 3,
                  "encoder_create: conv_kernel must be 3, 7, 15 or 31");
-    OASR_REQUIRE(cfg->left_max >= 0 && cfg->right_max >= 0 && cfg->left_max + cfg->right_max + 1 <= 96,
-                 "encoder_create: relative-position window too wide");
+    OASR_REQUIRE(cfg->left_max >= 0 && cfg->right_max >= 0 && cfg->left_max + cfg->right_max + 1 <= 80,
+                 "encoder_create: relative-position window wider than the 80 distances the attention kernel keeps");
     oasr_encoder* e = new (std::nothrow) oasr_encoder;
     if (!e) {
         set_error("encoder_create: out of host memory");

@@ -63,4 +63,12 @@ __device__ __forceinline__ float swishf(float x) { return x * sigmoidf(x); }
 
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
+// Greedy CTC decode (ctc.hip): argument checks shared by the entry points, and the two launches with the
+// per-frame winners going through `ids` (int32 [batch * t_pad], device).
+int ctc_check_args(const float* logits, int64_t ld, int32_t vocab, const int32_t* lengths, int32_t batch,
+                   int64_t t_pad, int32_t blank, int32_t* tokens, int32_t* frames, int32_t* counts);
+int ctc_launch(const float* logits, int64_t ld, int32_t vocab, const int32_t* lengths, int32_t batch,
+               int64_t t_pad, int32_t blank, int32_t* tokens, int32_t* frames, int32_t* counts,
+               int32_t* ids, hipStream_t stream);
+
 }  // namespace oasr

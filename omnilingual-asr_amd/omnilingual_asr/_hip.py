@@ -99,7 +99,8 @@ _SIGNATURES = {
     "oasr_resample_length": (c_i64, [c_i64, c_i32, c_i32]),
     "oasr_resample_poly": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp]),
     "oasr_cast_bf16": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
-    "oasr_ctc_greedy": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "oasr_ctc_workspace_bytes": (c_i64, [c_i32, c_i64]),
+    "oasr_ctc_greedy": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

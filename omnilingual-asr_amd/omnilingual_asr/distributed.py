@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-RECORD_WORDS = 6  # chunk_idx, valid, start_sample, end_sample, n_frames, activity (float64 bits)
+RECORD_WORDS = 5  # chunk_idx, valid, start_sample, end_sample, n_frames
 # A record may carry the chunk's CTC tokens after its header: word RECORD_WORDS holds the token count
 # (-1: the engine has no head), the following words hold (frame << 32 | token id), one per token.
 
@@ -40,7 +40,6 @@ def pack_records(records, capacity: int, token_capacity: int = 0) -> torch.Tenso
         buf[i, 2] = r.start_sample
         buf[i, 3] = r.end_sample
         buf[i, 4] = r.n_frames
-        buf[i, 5] = np.float64(r.activity).view(np.int64)
         if token_capacity > 0:
             if getattr(r, "tokens", None) is None:
                 buf[i, RECORD_WORDS] = -1
@@ -71,8 +70,7 @@ def unpack_records(gathered: torch.Tensor):
             packed = r[RECORD_WORDS + 1: RECORD_WORDS + 1 + n]
             tokens = (packed & 0xFFFFFFFF).astype(np.int32)
             frames = (packed >> 32).astype(np.int32)
-        out.append(ChunkRecord(int(r[0]), int(r[2]), int(r[3]), int(r[4]),
-                               float(np.int64(r[5]).view(np.float64)), tokens, frames))
+        out.append(ChunkRecord(int(r[0]), int(r[2]), int(r[3]), int(r[4]), tokens, frames))
     return out
 
 

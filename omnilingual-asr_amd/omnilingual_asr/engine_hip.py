@@ -86,7 +86,9 @@ class HipEngine:
     def _get_buffers(self, batch: int, n_samples_max: int):
         frames = _hip.num_frames(n_samples_max)
         t_pad = pad_frames(frames // 2)
-        frame_cap = 2 * t_pad
+        # even, and covers every frame of the widest row (2 * t_pad + 1 when the frame count is odd): the
+        # per-utterance statistics run over all frames whatever the row's batch neighbours are
+        frame_cap = 2 * t_pad + 2
         key = (batch, t_pad)
         buf = self._buffers.get(key)
         if buf is not None:
@@ -112,6 +114,8 @@ class HipEngine:
                 "tokens": torch.zeros((batch, t_pad), dtype=torch.int32, device=dev),
                 "tok_frames": torch.zeros((batch, t_pad), dtype=torch.int32, device=dev),
                 "counts": torch.zeros((batch,), dtype=torch.int32, device=dev),
+                "ctc_ids": torch.zeros((int(_hip.lib().oasr_ctc_workspace_bytes(batch, t_pad)) // 4,),
+                                       dtype=torch.int32, device=dev),
             }
             self._buffers[key] = buf
         return buf
@@ -208,7 +212,7 @@ class HipEngine:
         _hip.check(L.oasr_ctc_greedy(buf["logits"].data_ptr(), CTC_LOGIT_PITCH, self.geometry.vocab_size,
                                      _hip._ptr(lengths, torch.int32), batch, t_pad, tokenizer.BLANK,
                                      buf["tokens"].data_ptr(), buf["tok_frames"].data_ptr(),
-                                     buf["counts"].data_ptr(), st), "oasr_ctc_greedy")
+                                     buf["counts"].data_ptr(), buf["ctc_ids"].data_ptr(), st), "oasr_ctc_greedy")
         return buf["tokens"], buf["tok_frames"], buf["counts"]
 
     def step(self, pcm: torch.Tensor, n_valid: torch.Tensor):
@@ -257,7 +261,7 @@ class HipEngine:
             pcm_d.copy_(stage, non_blocking=True)
         if pcm_d.dim() != 2:
             raise ValueError("pcm must be [batch, samples]")
-        nv_host = torch.as_tensor(np.asarray(n_valid, dtype=np.int32))
+        nv_host = torch.as_tensor(self._checked_lengths(n_valid, pcm_d.shape[0], pcm_d.shape[1]))
         slot = self._pinned.get(tuple(pcm_d.shape))
         if slot is not None and slot[1].data_ptr() == pcm_d.data_ptr():
             slot[2].copy_(nv_host)
@@ -278,12 +282,26 @@ class HipEngine:
         return slot
 
     @staticmethod
+    def _checked_lengths(n_valid, batch: int, width: int) -> np.ndarray:
+        """int32 [batch] valid-sample counts; the kernels trust them, so they are checked here."""
+        nv = np.asarray(n_valid, dtype=np.int64).reshape(-1)
+        if nv.shape[0] != batch:
+            raise ValueError("n_valid has %d entries for a batch of %d" % (nv.shape[0], batch))
+        if nv.size and (nv.min() < 0 or nv.max() > width):
+            raise ValueError("n_valid must lie in [0, %d] (the batch width)" % width)
+        return nv.astype(np.int32)
+
+    @staticmethod
     def bucket_samples(n: int) -> int:
-        """The largest sample count that pads to the same number of encoder frames as `n`: batches
-        assembled at this width share buffers, slots and captured graphs across nearby lengths (at most
-        one shape per 32 encoder frames instead of one per distinct sample count)."""
-        t_pad = pad_frames(_hip.num_frames(max(int(n), 400)) // 2)
-        return 160 * (2 * t_pad - 1) + 400 + 156     # + 156: still 2 * t_pad frames, and a multiple of 4
+        """A batch width >= n (a multiple of 4) shared by every sample count that pads to the same number
+        of encoder frames: batches assembled at this width share buffers, slots and captured graphs across
+        nearby lengths (at most one shape per 32 encoder frames instead of one per distinct sample count)."""
+        n = max(int(n), 400)
+        t_pad = pad_frames(_hip.num_frames(n) // 2)
+        # a row pads to t_pad up to 2 * t_pad + 1 frames, i.e. up to 320 * t_pad + 559 samples; the last
+        # three of those do not fit a multiple of 4 and take the next bucket
+        width = 320 * t_pad + 556
+        return width if n <= width else 320 * (t_pad + 32) + 556
 
     def host_batch(self, b: int, n: int) -> np.ndarray:
         """A page-locked [b, round_up(n, 4)] float32 array to assemble a batch in; handing it (whole) to
@@ -313,8 +331,8 @@ class HipEngine:
             return hidden, lengths.cpu().numpy(), out
 
     # ---- two-deep asynchronous path -------------------------------------------------------------------
-    # submit() queues one batch (upload on a copy stream, device path, CTC stage, masked activity, results
-    # to page-locked memory) and returns at once; collect() waits for that batch only.  With two slots
+    # submit() queues one batch (upload on a copy stream, device path, CTC stage, results to page-locked
+    # memory) and returns at once; collect() waits for that batch only.  With two slots
     # the host assembles and uploads batch k+1 while the device works on batch k:
     #     a = host_batch_slot(b, n, 0); fill a; ta = submit(a-slot) ...
     # Intermediate device buffers are shared by both slots: batches run back to back on one stream.
@@ -330,7 +348,7 @@ class HipEngine:
                 "pcm_d": torch.zeros((b, n4), dtype=torch.float32, device=self.device),
                 "nv_d": torch.zeros((b,), dtype=torch.int32, device=self.device),
                 "tokens": pin((b, t_pad), torch.int32), "frames": pin((b, t_pad), torch.int32),
-                "counts": pin((b,), torch.int32), "lengths": pin((b,), torch.int32), "acts": pin((b,), torch.float64),
+                "counts": pin((b,), torch.int32), "lengths": pin((b,), torch.int32),
                 "copied": torch.cuda.Event(), "done": torch.cuda.Event(), "busy": False,
             }
             # the zero fills above are queued on the current stream, possibly behind a whole batch: the copy
@@ -359,7 +377,7 @@ class HipEngine:
             if self._copy_stream is None:
                 self._copy_stream = torch.cuda.Stream(self.device)
             main = torch.cuda.current_stream()
-            t["nv_pin"].numpy()[:] = np.asarray(n_valid, dtype=np.int32)
+            t["nv_pin"].numpy()[:] = self._checked_lengths(n_valid, *t["stage"].shape)
             self._copy_stream.wait_event(t["done"])      # the slot's device copy may still feed its previous batch
             with torch.cuda.stream(self._copy_stream):
                 t["pcm_d"].copy_(t["stage"], non_blocking=True)
@@ -368,22 +386,18 @@ class HipEngine:
             main.wait_event(t["copied"])
             hidden, lengths = self._run(t["pcm_d"], t["nv_d"])
             tok, frm, cnt = self.decode(hidden, lengths)
-            n = lengths.to(torch.int64)
-            per_frame = hidden.abs().sum(dim=-1).to(torch.float64)
-            mask = torch.arange(hidden.shape[1], device=self.device)[None, :] < n[:, None]
-            acts = (per_frame * mask).sum(dim=1) / (n * hidden.shape[2]).clamp(min=1).to(torch.float64)
-            for name, src in (("tokens", tok), ("frames", frm), ("counts", cnt), ("lengths", lengths), ("acts", acts)):
+            for name, src in (("tokens", tok), ("frames", frm), ("counts", cnt), ("lengths", lengths)):
                 t[name].copy_(src, non_blocking=True)
             t["done"].record()
             t["busy"] = True
 
     def collect(self, ticket):
-        """Wait for the ticket's batch: (lengths int32 [B], [(token ids, frame indices)] per row, mean
-        |state| per row).  The arrays are copies; the ticket can be reused at once."""
+        """Wait for the ticket's batch: (lengths int32 [B], [(token ids, frame indices)] per row).  The
+        arrays are copies; the ticket can be reused at once."""
         t = ticket
         t["done"].synchronize()
         t["busy"] = False
         cnt = t["counts"].numpy()
         tok, frm = t["tokens"].numpy(), t["frames"].numpy()
         toks = [(tok[i, : cnt[i]].copy(), frm[i, : cnt[i]].copy()) for i in range(tok.shape[0])]
-        return t["lengths"].numpy().copy(), toks, [float(v) for v in t["acts"].numpy()]
+        return t["lengths"].numpy().copy(), toks

@@ -234,7 +234,6 @@ class ChunkRecord:
     start_sample: int
     end_sample: int
     n_frames: int          # valid encoder frames (20 ms each)
-    activity: float        # mean |encoder state| over the valid frames
     tokens: Optional[np.ndarray] = None   # greedy CTC token ids (int32), None when the engine has no head
     frames: Optional[np.ndarray] = None   # encoder frame index of each token
 
@@ -255,6 +254,15 @@ class ChunkRecord:
         return GeminiTranscriptionResult(summary=None, segments=[seg], detected_languages=None)
 
 
+def _is_deterministic(exc: BaseException) -> bool:
+    """Errors that a second attempt or the next batch would meet again: a rejected kernel argument or an
+    unsupported shape (OasrError), a malformed batch (ValueError / TypeError), exhausted memory.  The
+    reference tolerates a failed chunk because its chunk is a network call (ref :635-641); none of
+    these is that kind of failure, so they are never swallowed."""
+    from omnilingual_asr._hip import OasrError
+    return isinstance(exc, (OasrError, ValueError, TypeError, AssertionError, MemoryError))
+
+
 class GeminiASRPipeline:
     """Drop-in for the reference's engine class (ref gemini_pipeline.py:313-741) running locally.
 
@@ -262,7 +270,14 @@ class GeminiASRPipeline:
     engine needs none).  `model` names an encoder geometry ("G300", "G7B"); the reference's remote
     model names select the default.  `engine` may be injected (anything with
     `encode_batch(pcm[B,N], n_valid) -> (hidden[B,T,d], lengths)`); by default a `HipEngine` is
-    created on first use and its absence (no library, no GPU) is an error."""
+    created on first use and its absence (no library, no GPU) is an error.
+
+    `chunk_seconds` / `min_chunking_seconds` default to 30 s / 30 s — the utterance length the encoder
+    is sized and measured for — not to the reference's 300 s / 360 s (`CHUNK_DURATION_SECONDS`,
+    `MIN_DURATION_FOR_CHUNKING`, ref :217-218).  Consequence: a file between 30 s and 360 s comes back
+    as one segment per 30 s where the reference returns what its remote model segments; pass
+    `chunk_seconds=300, min_chunking_seconds=360` for the reference's plan (every chunk length runs on
+    the device path)."""
 
     def __init__(self, api_key: Optional[str] = None, model: str = "gemini-3-flash-preview", *,
                  engine: Any = None, device: Any = None, chunk_seconds: float = DEFAULT_CHUNK_SECONDS,
@@ -292,55 +307,64 @@ class GeminiASRPipeline:
     def _encode_chunks(self, pcm: np.ndarray, bounds: np.ndarray, first_idx: int = 0) -> List[ChunkRecord]:
         """Run the chunks `bounds[i] = (start, end)` of `pcm` through the engine in batches.  An engine
         with `submit`/`collect` is driven two batches deep: batch k+1 is assembled in page-locked memory
-        and uploaded while the device works on batch k."""
+        and uploaded while the device works on batch k.  A batch whose engine call fails with an error
+        that is not deterministic (see `_is_deterministic`) is reported and skipped, as the reference skips
+        a failed chunk (ref :635-641); deterministic errors propagate."""
         records: List[ChunkRecord] = []
         n = len(bounds)
         pipelined = hasattr(self.engine, "submit")
 
-        def finish(lo, part, lengths, toks, acts):
+        def finish(lo, part, lengths, toks):
             for i, (s, e) in enumerate(part):
-                records.append(ChunkRecord(first_idx + lo + i, int(s), int(e), int(lengths[i]), float(acts[i]),
+                records.append(ChunkRecord(first_idx + lo + i, int(s), int(e), int(lengths[i]),
                                            toks[i][0], toks[i][1]))
+
+        def tolerate(exc):
+            if _is_deterministic(exc):
+                raise exc
+            print(f"Chunk transcription failed: {exc}")
 
         def collect(job):
             lo, part, ticket = job
             try:
                 finish(lo, part, *self.engine.collect(ticket))
-            except Exception as exc:  # per-batch failure is tolerated, as per-chunk failure is in
-                print(f"Chunk transcription failed: {exc}")   # the reference (ref :635-641)
+            except Exception as exc:
+                tolerate(exc)
 
         in_flight = None
         lock = self._engine_lock if pipelined else contextlib.nullcontext()
         with lock:      # the two-deep path keeps the engine for the whole file
             for k, lo in enumerate(range(0, n, self.batch_size)):
                 part = bounds[lo: lo + self.batch_size]
-                width = max(int(max(e - s for s, e in part)), 400)
+                longest = max(int(max(e - s for s, e in part)), 400)
+                width = longest
                 if hasattr(self.engine, "bucket_samples"):     # nearby lengths share one device shape
-                    width = self.engine.bucket_samples(width)
+                    width = self.engine.bucket_samples(longest)
+                if width < longest:
+                    raise ValueError("batch width %d does not cover its longest chunk (%d samples)" % (width, longest))
                 n_valid = [int(e - s) for s, e in part]
+                if pipelined:
+                    ticket, batch = self.engine.host_batch_slot(len(part), width, k)
+                else:
+                    ticket, batch = None, np.empty((len(part), width), dtype=np.float32)
+                for i, (s, e) in enumerate(part):
+                    batch[i, : e - s] = pcm[s:e]
+                    batch[i, e - s:] = 0.0
+                job = None
                 try:
-                    if pipelined:
-                        ticket, batch = self.engine.host_batch_slot(len(part), width, k)
-                    else:
-                        ticket, batch = None, np.empty((len(part), width), dtype=np.float32)
-                    for i, (s, e) in enumerate(part):
-                        batch[i, : e - s] = pcm[s:e]
-                        batch[i, e - s:] = 0.0
                     if pipelined:
                         self.engine.submit(ticket, n_valid)
                         job = (lo, part, ticket)
                     else:
                         with self._engine_lock:
                             if hasattr(self.engine, "transcribe_batch"):
-                                hidden, lengths, toks = self.engine.transcribe_batch(batch, n_valid)
+                                _, lengths, toks = self.engine.transcribe_batch(batch, n_valid)
                             else:
-                                hidden, lengths = self.engine.encode_batch(batch, n_valid)
+                                _, lengths = self.engine.encode_batch(batch, n_valid)
                                 toks = [(None, None)] * len(part)
-                            finish(lo, part, lengths, toks, _mean_abs(hidden, lengths))
-                        job = None
+                            finish(lo, part, lengths, toks)
                 except Exception as exc:
-                    print(f"Chunk transcription failed: {exc}")
-                    job = None
+                    tolerate(exc)
                 if in_flight is not None:
                     collect(in_flight)
                 in_flight = job
@@ -357,23 +381,36 @@ class GeminiASRPipeline:
                     return self.engine.resample_16k(mono, rate).cpu().numpy()
         return _audio.load_audio_16k(Path(audio_path), resampler)
 
-    # ---- single-utterance path (ref :474-539) -----------------------------------------------------------
+    def _encode_file(self, pcm: np.ndarray, word_timestamps: bool) -> GeminiTranscriptionResult:
+        """Plan on the decoded sample count, encode (this rank's shard when a process group is set),
+        shift every chunk to file time and merge (ref :541-575, :646-678).  The header duration only
+        picks the entry point (ref :713-714); a header that could not be read (duration 0.0) must not
+        turn hours of audio into one utterance, so the plan is made here, from the samples."""
+        bounds = plan_chunks(pcm.shape[0], self.chunk_seconds, self.min_chunking_seconds)
+        if self.process_group is not None and len(bounds) > 1:
+            from omnilingual_asr import distributed as _dist
+            records = _dist.encode_sharded(self, pcm, bounds, self.process_group)
+        else:
+            records = self._encode_chunks(pcm, bounds)
+        if not records:
+            raise RuntimeError("none of the %d chunk(s) could be transcribed" % len(bounds))
+        if len(bounds) == 1:
+            return records[0].to_result(word_timestamps=word_timestamps)
+        return merge_results([self._transcribe_chunk(r, word_timestamps) for r in records])
+
+    # ---- single-utterance entry (ref :474-539) ----------------------------------------------------------
     def transcribe(self, audio_path, *, progress_callback: Optional[Callable[[str, int], None]] = None,
                    language: Optional[str] = None, speaker_count: Optional[str] = None,
-                   word_timestamps: bool = False) -> GeminiTranscriptionResult:
+                   word_timestamps: bool = False, _pcm: Optional[np.ndarray] = None) -> GeminiTranscriptionResult:
         def report(step, idx):
             if progress_callback:
                 progress_callback(step, idx)
 
         report("uploading", 0)
-        pcm = self._load_audio(audio_path)
+        pcm = self._load_audio(audio_path) if _pcm is None else _pcm
         report("transcribing", 1)
-        bounds = np.array([[0, pcm.shape[0]]], dtype=np.int64)
-        with_state = self._encode_chunks(pcm, bounds)
-        if not with_state:
-            raise RuntimeError("encoder produced no output for " + str(audio_path))
+        result = self._encode_file(pcm, word_timestamps)
         report("processing", 2)
-        result = with_state[0].to_result(word_timestamps=word_timestamps)
         report("done", 3)
         return result
 
@@ -382,7 +419,7 @@ class GeminiASRPipeline:
         return offset_result(record.to_result(word_timestamps=word_timestamps),
                              record.start_sample / float(SAMPLE_RATE))
 
-    # ---- long-audio path (ref :577-682) -----------------------------------------------------------------
+    # ---- long-audio entry (ref :577-682) ----------------------------------------------------------------
     def transcribe_chunked(self, audio_path, *, progress_callback: Optional[Callable[[str, int], None]] = None,
                            language: Optional[str] = None, speaker_count: Optional[str] = None,
                            word_timestamps: bool = False) -> GeminiTranscriptionResult:
@@ -394,18 +431,14 @@ class GeminiASRPipeline:
         pcm = self._load_audio(audio_path)
         bounds = plan_chunks(pcm.shape[0], self.chunk_seconds, self.min_chunking_seconds)
         if len(bounds) <= 1:
-            # same fall-through as the reference (ref :609-616), including its repeated progress steps
+            # same fall-through as the reference (ref :609-616), including its repeated progress steps;
+            # the samples decoded above are handed over, not decoded again
             return self.transcribe(audio_path, progress_callback=progress_callback,
                                    language=language, speaker_count=speaker_count,
-                                   word_timestamps=word_timestamps)
+                                   word_timestamps=word_timestamps, _pcm=pcm)
         report("transcribing", 1)
-        if self.process_group is not None:
-            from omnilingual_asr import distributed as _dist
-            records = _dist.encode_sharded(self, pcm, bounds, self.process_group)
-        else:
-            records = self._encode_chunks(pcm, bounds)
+        merged = self._encode_file(pcm, word_timestamps)
         report("processing", 2)
-        merged = merge_results([self._transcribe_chunk(r, word_timestamps) for r in records])
         report("done", 3)
         return merged
 
@@ -432,16 +465,3 @@ class GeminiASRPipeline:
 
 
 ASRPipeline = GeminiASRPipeline
-
-
-def _mean_abs(hidden, lengths) -> List[float]:
-    """Mean |state| over each utterance's valid frames: one masked reduction and one copy per batch."""
-    import torch
-
-    h = hidden if isinstance(hidden, torch.Tensor) else torch.as_tensor(hidden)
-    n = torch.as_tensor(np.asarray(lengths, dtype=np.int64), device=h.device)
-    per_frame = h.abs().sum(dim=-1).to(torch.float64)                                     # [B, T]
-    mask = torch.arange(h.shape[1], device=h.device)[None, :] < n[:, None]
-    total = (per_frame * mask).sum(dim=1)
-    denom = (n * h.shape[2]).clamp(min=1).to(torch.float64)
-    return [float(v) for v in (total / denom).cpu()]

@@ -69,3 +69,19 @@ def test_feature_tables_match_oracle():
     blob = _hip.logmel_table_blob()
     assert blob.dtype == np.uint32 and blob.size == int(_hip.lib().oasr_logmel_table_words())
     np.testing.assert_array_equal(blob[:400].view(np.float32), win)
+
+
+def test_bucket_width_covers_every_sample_count():
+    """`HipEngine.bucket_samples(n)` is a multiple of 4, at least n, and pads to the same number of
+    encoder frames as n or to the next bucket — for every n (exhaustive over 0.4 s .. 4 s, sampled
+    beyond, including a 300 s chunk)."""
+    from omnilingual_asr import _hip
+    from omnilingual_asr.engine_hip import HipEngine, pad_frames
+
+    t_of = lambda n: pad_frames(_hip.num_frames(n) // 2)
+    ns = list(range(1, 64000)) + [480000, 4800000, 4800001, 4802556, 4802557, 4802559, 4802560]
+    for n in ns:
+        w = HipEngine.bucket_samples(n)
+        assert w % 4 == 0 and w >= n, n
+        assert t_of(w) in (t_of(max(n, 400)), t_of(max(n, 400)) + 32), n
+        assert HipEngine.bucket_samples(w) == w, n          # a bucket is its own bucket

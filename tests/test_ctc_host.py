@@ -41,9 +41,9 @@ def test_greedy_rule_known_answers():
 
 
 def test_records_carry_tokens_through_pack_unpack():
-    recs = [ChunkRecord(3, 0, 480000, 1499, 0.5, np.array([5, 1, 7], np.int32), np.array([2, 900, 1498], np.int32)),
-            ChunkRecord(1, 480000, 960000, 1499, 0.25, np.zeros((0,), np.int32), np.zeros((0,), np.int32)),
-            ChunkRecord(2, 960000, 961000, 3, 0.0, None, None)]
+    recs = [ChunkRecord(3, 0, 480000, 1499, np.array([5, 1, 7], np.int32), np.array([2, 900, 1498], np.int32)),
+            ChunkRecord(1, 480000, 960000, 1499, np.zeros((0,), np.int32), np.zeros((0,), np.int32)),
+            ChunkRecord(2, 960000, 961000, 3, None, None)]
     packed = D.pack_records(recs, capacity=5, token_capacity=1500)
     assert packed.shape == (5, D.RECORD_WORDS + 1 + 1500) and packed.dtype == torch.int64
     back = D.unpack_records(torch.cat([packed, torch.zeros_like(packed)]))

@@ -81,10 +81,76 @@ def test_record_pack_roundtrip_and_order():
     from omnilingual_asr import distributed as D
     from omnilingual_asr.models.inference.asr_pipeline import ChunkRecord
 
-    a = [ChunkRecord(4, 400, 500, 3, 0.25), ChunkRecord(5, 500, 600, 2, 1e-7)]
-    b = [ChunkRecord(0, 0, 100, 7, 3.5)]
+    a = [ChunkRecord(4, 400, 500, 3), ChunkRecord(5, 500, 600, 2)]
+    b = [ChunkRecord(0, 0, 100, 7)]
     gathered = torch.cat([D.pack_records(a, 3), D.pack_records(b, 3)])
     got = D.unpack_records(gathered)
     assert [r.chunk_idx for r in got] == [0, 4, 5]
-    assert got[1] == a[0] and got[2] == a[1] and got[0] == b[0]   # float64 activity survives bit-exactly
+    assert got[1] == a[0] and got[2] == a[1] and got[0] == b[0]
     assert D.max_shard(1140, 8) == 143
+
+
+class _PlanEngine:
+    """Stands in for the device: frame counts from the sample counts, tokens that name the chunk (its
+    first sample in 30 s units), so the merged order and the token transport can be checked without
+    running an encoder 1 140 times."""
+
+    def __init__(self):
+        self.batches = []
+
+    def transcribe_batch(self, pcm, n_valid):
+        n_valid = np.asarray(n_valid)
+        self.batches.append(len(n_valid))
+        lengths = np.array([max(0, (int(n) - 400) // 160 + 1) // 2 if n >= 400 else 0 for n in n_valid], dtype=np.int32)
+        toks = []
+        for i in range(len(n_valid)):
+            tag = int(round(float(pcm[i, 0])))             # each chunk's first sample holds its index
+            toks.append((np.array([tag % 29 + 2, tag // 29 + 2, 5], dtype=np.int32), np.array([0, 1, 7], dtype=np.int32)))
+        return None, lengths, toks
+
+
+def _worker8(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    for p in (str(ROOT), str(ROOT / "omnilingual-asr_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from omnilingual_asr import distributed as D
+    from omnilingual_asr.models.inference.asr_pipeline import GeminiASRPipeline, plan_chunks
+
+    calls = []
+    real = dist.all_gather
+    dist.all_gather = lambda *a, **k: (calls.append("all_gather"), real(*a, **k))[1]
+    chunk, n_chunks = 4000, 1140                  # the 9.5 h plan's shape at 0.25 s per chunk
+    bounds = plan_chunks(chunk * n_chunks - 1500, chunk / 16000.0, 0.0)
+    pcm = np.zeros(chunk * n_chunks, dtype=np.float32)
+    pcm[::chunk] = np.arange(n_chunks, dtype=np.float32)
+    eng = _PlanEngine()
+    pipe = GeminiASRPipeline(engine=eng, chunk_seconds=chunk / 16000.0, min_chunking_seconds=0.0, batch_size=32)
+    recs = D.encode_sharded(pipe, pcm, bounds, dist.group.WORLD)
+    dist.all_gather = real
+    torch.save({"n_bounds": len(bounds), "batches": eng.batches, "calls": calls,
+                "idx": [r.chunk_idx for r in recs], "starts": [r.start_sample for r in recs],
+                "ends": [r.end_sample for r in recs], "frames": [r.n_frames for r in recs],
+                "tags": [int((r.tokens[0] - 2) + 29 * (r.tokens[1] - 2)) for r in recs],
+                "tok_frames": [r.frames.tolist() for r in recs[:3]]}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_shard_the_1140_chunk_plan_with_one_all_gather(tmp_path):
+    """World size 8 on the 1 140-chunk plan (shards of 143/142 chunks, four full batches of 32 and a tail
+    of 15 or 14 per rank, token-carrying records): every rank ends with all records in chunk order, and
+    the data path issues exactly one all_gather."""
+    port = _free_port()
+    mp.spawn(_worker8, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    outs = [torch.load(tmp_path / f"r{r}.pt") for r in range(8)]
+    for r, o in enumerate(outs):
+        assert o["n_bounds"] == 1140 and o["calls"] == ["all_gather"]
+        assert o["batches"] == [32, 32, 32, 32, 15 if r < 4 else 14]
+        assert o["idx"] == list(range(1140)) and o["tags"] == list(range(1140))
+        assert o["starts"] == [4000 * i for i in range(1140)]
+        assert o["ends"][-1] == 4000 * 1140 - 1500 and o["ends"][:-1] == [4000 * (i + 1) for i in range(1139)]
+        assert o["frames"][0] == 11 and o["frames"][-1] == ((2500 - 400) // 160 + 1) // 2
+        assert o["tok_frames"] == [[0, 1, 7]] * 3

@@ -34,6 +34,9 @@ def test_cast_bf16_rounds_to_nearest_even():
     (2, 1504, 32, 256, [1499, 878]),
     (2, 96, 300, 304, [96, 50]),
     (1, 8192, 5, 8, [8000]),
+    (2, 15008, 32, 32, [14999, 9001]),          # a 300 s chunk of the reference's plan: 15 008 frames
+    (1, 2049, 70, 72, [2049]),                  # one frame past a collapse tile; 70 columns on 32 lanes
+    (3, 40, 1000, 1000, [40, 0, 17]),           # several loads per lane; an empty utterance
 ])
 def test_ctc_greedy_bit_exact(batch, t_pad, vocab, ld, lens):
     from oracle import ctc
@@ -50,14 +53,16 @@ def test_ctc_greedy_bit_exact(batch, t_pad, vocab, ld, lens):
     tok = torch.full((batch, t_pad), 7, dtype=torch.int32, device="cuda")
     frm = torch.full((batch, t_pad), 7, dtype=torch.int32, device="cuda")
     cnt = torch.zeros((batch,), dtype=torch.int32, device="cuda")
+    assert H.lib().oasr_ctc_workspace_bytes(batch, t_pad) == 4 * batch * t_pad
+    ws = torch.full((batch * t_pad,), -5, dtype=torch.int32, device="cuda")
     H.check(H.lib().oasr_ctc_greedy(lg_d.data_ptr(), ld, vocab, len_d.data_ptr(), batch, t_pad, 0,
-                                    tok.data_ptr(), frm.data_ptr(), cnt.data_ptr(), _stream()))
+                                    tok.data_ptr(), frm.data_ptr(), cnt.data_ptr(), ws.data_ptr(), _stream()))
     torch.cuda.synchronize()
     ref = ctc.greedy(lg[:, :, :vocab].numpy(), lens, blank=0)
     tok, frm, cnt = tok.cpu().numpy(), frm.cpu().numpy(), cnt.cpu().numpy()
     for b in range(batch):
         n = len(ref[b][0])
-        assert cnt[b] == n and n > 0
+        assert cnt[b] == n and (n > 0 or lens[b] == 0)
         np.testing.assert_array_equal(tok[b, :n], ref[b][0])
         np.testing.assert_array_equal(frm[b, :n], ref[b][1])
         assert (tok[b, n:] == -1).all() and (frm[b, n:] == -1).all()
@@ -68,8 +73,9 @@ def test_ctc_greedy_rejects_bad_arguments():
     z = torch.zeros((64, 256), device="cuda")
     i = torch.zeros((64,), dtype=torch.int32, device="cuda")
     args = lambda **kw: (z.data_ptr(), kw.get("ld", 256), kw.get("vocab", 32), i.data_ptr(), 1, kw.get("t_pad", 64),
-                         kw.get("blank", 0), i.data_ptr(), i.data_ptr(), i.data_ptr(), _stream())
-    assert H.lib().oasr_ctc_greedy(*args(t_pad=8193)) == -1
+                         kw.get("blank", 0), i.data_ptr(), i.data_ptr(), i.data_ptr(), kw.get("ws", i.data_ptr()), _stream())
+    assert H.lib().oasr_ctc_greedy(*args(t_pad=0)) == -1
+    assert H.lib().oasr_ctc_greedy(*args(ws=None)) == -1
     assert H.lib().oasr_ctc_greedy(*args(blank=32)) == -1
     assert H.lib().oasr_ctc_greedy(*args(ld=30)) == -1
     assert b"ld" in H.lib().oasr_last_error()

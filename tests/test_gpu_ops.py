@@ -305,6 +305,46 @@ def test_attention_relkey(batch, t_pad, lens, heads, head):
     assert torch.isfinite(got).all()
 
 
+def test_attention_at_the_reference_chunk_length():
+    """One head over 15 008 keys — a 300 s chunk of the reference's plan (ref gemini_pipeline.py:217) —
+    against a float64 reference computed in blocks of 1024 queries.  Queries are scaled up so the
+    softmax is peaked and the result is not just the mean of V.  Tolerance: relative L2 <= 1.5e-2 and
+    3e-2 absolute (P and the output are rounded to bf16)."""
+    H = _lib()
+    t_pad, n, head = 15008, 14999, 64
+    g = torch.Generator().manual_seed(77)
+    qkv = torch.randn((1, t_pad, 3 * head), generator=g)
+    qkv[..., :head] *= 3.0
+    qkv, qkv_ref = _prescale_q(qkv, head, head)
+    emb = torch.zeros((96, head))
+    emb[:73] = torch.randn((73, head), generator=g) * (8.0 / math.sqrt(head))
+    emb = _bf(emb)
+    lengths = torch.tensor([n], dtype=torch.int32)
+    rows = (t_pad + 255) // 256 * 256
+    qkv_d = torch.zeros((rows, 3 * head), dtype=torch.bfloat16, device="cuda")
+    qkv_d[:t_pad] = qkv.reshape(-1, 3 * head).cuda()
+    ctx = torch.zeros((rows, head), dtype=torch.bfloat16, device="cuda")
+    emb_d, len_d = emb.cuda(), lengths.cuda()
+    H.check(H.lib().oasr_attention_relkey(qkv_d.data_ptr(), emb_d.data_ptr(), len_d.data_ptr(),
+                                          ctx.data_ptr(), 1, t_pad, 1, head, 64, 8, _stream()))
+    torch.cuda.synchronize()
+    q, k, v = [x[0].double() for x in qkv_ref.split(head, dim=-1)]
+    e = emb.double()[:73]
+    want = torch.zeros((n, head), dtype=torch.float64)
+    keys = torch.arange(n)
+    for q0 in range(0, n, 1024):
+        qb = q[q0: q0 + 1024][: n - q0]
+        dist = (keys[None, :] - (q0 + torch.arange(qb.shape[0]))[:, None]).clamp(-64, 8) + 64
+        sc = (qb @ k[:n].t() + torch.gather(qb @ e.t(), 1, dist)) / math.sqrt(head)
+        want[q0: q0 + qb.shape[0]] = torch.softmax(sc, dim=-1) @ v[:n]
+    got = ctx[:n].float().cpu().double()
+    assert torch.isfinite(ctx.float()).all()
+    rel = float((got - want).norm() / want.norm())
+    assert rel <= 1.5e-2, rel
+    torch.testing.assert_close(got, want, atol=3e-2, rtol=3e-2)
+    assert float(want.abs().mean()) > 0.05          # the case is not the flat-softmax one
+
+
 @pytest.mark.parametrize("d", [64, 128])
 def test_attention_online_softmax_rescale_is_exercised(d):
     """A key late in the sequence that dominates every row forces the running maximum to jump at a

@@ -45,7 +45,7 @@ def test_ctc_greedy_on_random_logits():
     st = torch.cuda.current_stream().cuda_stream
     for trial in range(12):
         batch = int(rng.integers(1, 5))
-        t_pad = int(rng.integers(1, 40)) * 32
+        t_pad = int(rng.integers(1, 40)) * 32 if trial % 3 else int(rng.integers(1, 5000))   # any pitch, past a collapse tile
         vocab = int(rng.integers(2, 200))
         ld = (vocab + 3) // 4 * 4 + 4 * int(rng.integers(0, 3))
         lens = [int(rng.integers(0, t_pad + 1)) for _ in range(batch)]
@@ -56,8 +56,9 @@ def test_ctc_greedy_on_random_logits():
         tok = torch.full((batch, t_pad), 9, dtype=torch.int32, device="cuda")
         frm = torch.full((batch, t_pad), 9, dtype=torch.int32, device="cuda")
         cnt = torch.full((batch,), -3, dtype=torch.int32, device="cuda")
+        ws = torch.full((batch * t_pad,), 123, dtype=torch.int32, device="cuda")
         H.check(H.lib().oasr_ctc_greedy(lg_d.data_ptr(), ld, vocab, len_d.data_ptr(), batch, t_pad, 0,
-                                        tok.data_ptr(), frm.data_ptr(), cnt.data_ptr(), st))
+                                        tok.data_ptr(), frm.data_ptr(), cnt.data_ptr(), ws.data_ptr(), st))
         torch.cuda.synchronize()
         ref = ctc.greedy(lg[:, :, :vocab], lens, blank=0)
         tok, frm, cnt = tok.cpu().numpy(), frm.cpu().numpy(), cnt.cpu().numpy()

@@ -182,7 +182,7 @@ def test_failed_batch_is_skipped_like_a_failed_chunk(tiny_engine, tmp_path, caps
         def encode_batch(self, pcm, n_valid):
             self.n += 1
             if self.n == 2:
-                raise ValueError("boom")
+                raise RuntimeError("boom")               # the device hiccup kind: tolerated per batch
             return self.inner.encode_batch(pcm, n_valid)
 
     wav = tmp_path / "long.wav"
@@ -191,6 +191,54 @@ def test_failed_batch_is_skipped_like_a_failed_chunk(tiny_engine, tmp_path, caps
     segs = pipe.transcribe(str(wav))
     assert [s.start for s in segs] == [0.0, 4.0]
     assert "Chunk transcription failed: boom" in capsys.readouterr().out
+
+
+def test_deterministic_engine_errors_are_not_swallowed(tiny_engine, tmp_path, monkeypatch):
+    """A rejected kernel argument (OasrError) or a malformed batch is not a failed network call: it
+    propagates (and ends as the reference's final RuntimeError), and a file whose every chunk fails
+    raises instead of returning an empty transcript."""
+    import time
+    from omnilingual_asr._hip import OasrError
+    monkeypatch.setattr(time, "sleep", lambda s: None)
+
+    class Rejecting:
+        def encode_batch(self, pcm, n_valid):
+            raise OasrError("oasr_ctc_greedy failed (-1): t_pad out of range")
+
+    class Down:
+        def encode_batch(self, pcm, n_valid):
+            raise RuntimeError("device lost")
+
+    wav = tmp_path / "long.wav"
+    _write_wav(wav, 6.0)
+    for eng, text in ((Rejecting(), "t_pad out of range"), (Down(), "none of the 3 chunk(s) could be transcribed")):
+        pipe = Pipeline(engine=eng, chunk_seconds=2.0, min_chunking_seconds=3.0, batch_size=1)
+        with pytest.raises(RuntimeError) as ei:
+            pipe.transcribe(str(wav))
+        assert str(ei.value).startswith("Failed to transcribe after 3 attempts: ") and text in str(ei.value)
+    with pytest.raises(OasrError):
+        GeminiASRPipeline(engine=Rejecting(), chunk_seconds=2.0, min_chunking_seconds=3.0)._encode_chunks(
+            np.zeros(64000, dtype=np.float32), np.array([[0, 32000], [32000, 64000]]))
+
+
+def test_unreadable_header_still_chunks_on_the_decoded_length(tiny_engine, tmp_path, monkeypatch):
+    """The duration probe returns 0.0 when it cannot read the header (ref :222-240), which sends the file
+    down the single-utterance entry; the plan is made from the decoded samples, so the file is still cut
+    into chunks and decoded once."""
+    wav = tmp_path / "long.wav"
+    _write_wav(wav, 7.3)
+    monkeypatch.setattr(AP, "get_audio_duration", lambda p: 0.0)
+    loads = []
+    real = AP._audio.load_audio_16k
+    monkeypatch.setattr(AP._audio, "load_audio_16k", lambda *a, **k: (loads.append(1), real(*a, **k))[1])
+    pipe = Pipeline(engine=tiny_engine, chunk_seconds=2.0, min_chunking_seconds=3.0, batch_size=3)
+    progress = []
+    segs = pipe.transcribe(str(wav), progress_callback=lambda s, i: progress.append((s, i)))
+    assert [s.start for s in segs] == [0.0, 2.0, 4.0, 6.0] and len(loads) == 1
+    assert progress == [("uploading", 0), ("transcribing", 1), ("processing", 2), ("done", 3)]
+    loads.clear()
+    GeminiASRPipeline(engine=tiny_engine).transcribe_chunked(wav)      # fall-through: still one decode
+    assert len(loads) == 1
 
 
 def test_concurrent_calls_on_one_instance(tiny_engine, golden_dir):

@@ -62,7 +62,6 @@ def test_record_packing_round_trip(data):
         frames = sorted(data.draw(st.lists(st.integers(0, 1498), min_size=k, max_size=k)))
         recs.append(ChunkRecord(data.draw(st.integers(0, 10 ** 6)), data.draw(st.integers(0, 2 ** 40)),
                                 data.draw(st.integers(0, 2 ** 40)), data.draw(st.integers(0, 1499)),
-                                data.draw(st.floats(0, 1e6, allow_nan=False)),
                                 np.asarray(toks, dtype=np.int32), np.asarray(frames, dtype=np.int32)))
     back = odist.unpack_records(odist.pack_records(recs, n + 2, 12))
     want = sorted(recs, key=lambda r: r.chunk_idx)
@@ -70,6 +69,6 @@ def test_record_packing_round_trip(data):
     for a, b in zip(back, sorted(want, key=lambda r: r.chunk_idx)):
         if [r.chunk_idx for r in recs].count(a.chunk_idx) > 1:
             continue                                   # duplicate indices: order among equals is the input order
-        assert (a.chunk_idx, a.start_sample, a.end_sample, a.n_frames, a.activity) == \
-               (b.chunk_idx, b.start_sample, b.end_sample, b.n_frames, b.activity)
+        assert (a.chunk_idx, a.start_sample, a.end_sample, a.n_frames) == \
+               (b.chunk_idx, b.start_sample, b.end_sample, b.n_frames)
         assert a.tokens.tolist() == b.tokens.tolist() and a.frames.tolist() == b.frames.tolist()

@@ -14,11 +14,11 @@ local = int(os.environ.get("LOCAL_RANK", "0"))
 torch.cuda.set_device(local)
 dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 dist.barrier()
-recs = [ChunkRecord(i, i * 480000, (i + 1) * 480000, 1499, 0.5 + i, np.arange(5, dtype=np.int32) + i,
+recs = [ChunkRecord(i, i * 480000, (i + 1) * 480000, 1499, np.arange(5, dtype=np.int32) + i,
                     np.arange(5, dtype=np.int32) * 3) for i in range(4)]
 g = odist.all_gather_records(odist.pack_records(recs, 6, 16))
 back = odist.unpack_records(g)
-assert [r.chunk_idx for r in back] == [0, 1, 2, 3] and back[2].activity == 2.5 and list(back[3].tokens) == [3, 4, 5, 6, 7]
+assert [r.chunk_idx for r in back] == [0, 1, 2, 3] and list(back[3].tokens) == [3, 4, 5, 6, 7]
 t = torch.tensor([1.25], dtype=torch.float64, device="cuda")
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
 assert float(t.item()) == 1.25
