@@ -16,7 +16,9 @@
  *   - no function allocates or frees device memory, synchronises the device or blocks on the
  *     stream, except oasr_encoder_create/destroy (host memory only) — so every launch function
  *     may be captured into a hipGraph by the caller
- *   - thread-compatible: no mutable global state; an encoder handle is immutable after create
+ *   - thread-compatible: no mutable global state; an encoder handle is immutable after create.
+ *     One exception, documented at its declaration: oasr_ctc_greedy_static works in a per-GPU array
+ *     the library owns
  */
 #ifndef OASR_H
 #define OASR_H
@@ -296,6 +298,19 @@ int64_t oasr_ctc_workspace_bytes(int32_t batch, int64_t t_pad);
 int oasr_ctc_greedy(const float* logits, int64_t ld, int32_t vocab, const int32_t* lengths,
                     int32_t batch, int64_t t_pad, int32_t blank, int32_t* tokens, int32_t* frames,
                     int32_t* counts, void* workspace, void* stream);
+
+/* The same decode for callers that cannot allocate device memory: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Takes no
+ * workspace: the per-frame winners go to an array the library holds on each GPU it runs on (4 MiB,
+ * until the process ends), so batch * t_pad must not exceed oasr_ctc_static_max_frames() (1 048 576;
+ * OASR_ECAPACITY otherwise) — a batch of 32 x 30 s is 48 128 frames.  Results are identical to
+ * oasr_ctc_greedy's.  Calls no hipMalloc / hipFree.  Every call on a GPU shares that GPU's array: calls
+ * that overlap on one GPU (two streams, two threads) race; serialise them.  The first call on a device
+ * resolves the array's address (hipGetSymbolAddress) — make it outside stream capture. */
+int64_t oasr_ctc_static_max_frames(void);
+int oasr_ctc_greedy_static(const float* logits, int64_t ld, int32_t vocab, const int32_t* lengths,
+                           int32_t batch, int64_t t_pad, int32_t blank, int32_t* tokens,
+                           int32_t* frames, int32_t* counts, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Sample-rate conversion to 16 kHz on the device.  The reference sends the file as it is to its

@@ -100,6 +100,8 @@ _SIGNATURES = {
     "oasr_resample_poly": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp]),
     "oasr_cast_bf16": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     "oasr_ctc_workspace_bytes": (c_i64, [c_i32, c_i64]),
+    "oasr_ctc_static_max_frames": (c_i64, []),
+    "oasr_ctc_greedy_static": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "oasr_ctc_greedy": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
 }
 
