@@ -75,36 +75,92 @@ def measured_traffic(kernel: str, shape: str):
     return entry["traffic_bytes_per_launch"]
 
 
+def _time_launches(prep, launch, iters: int = 20) -> float:
+    """Average milliseconds of `launch()` over `iters` launches, each bracketed by its own pair of HIP
+    events on the stream the kernel runs on (torch's current stream) and preceded, outside the events,
+    by `prep()` — the kernel that produces its input in the encoder, so operands are as cache-warm as
+    in the step."""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters + 1)]
+    for e0, e1 in ev:
+        if prep is not None:
+            prep()
+        e0.record()
+        launch()
+        e1.record()
+    torch.cuda.synchronize()
+    return sum(e0.elapsed_time(e1) for e0, e1 in ev[1:]) / iters
+
+
 def kernel_rooflines(engine, batch: int, t_pad: int, pcm, nv, hidden) -> dict:
-    """HIP-event timings of the two kernels that bound the path: the FFN up-projection GEMM
-    (MFMA-bound, the dominant kernel) and the log-mel kernel (HBM-bound)."""
+    """HIP-event timings of the kernels that bound the path.  `roofline` is the dominant kernel, the FFN
+    up-projection GEMM (MFMA-bound); `roofline_more` holds the other GEMM shapes of a block (FFN down
+    and the d x d projection, both with the float32 residual epilogue), the attention kernel and the
+    feature kernel (HBM-bound)."""
     from omnilingual_asr import _hip
     g = engine.geometry
     L = _hip.lib()
     rows = int(L.oasr_encoder_rows(batch, t_pad))
     dev = engine.device
     lw = engine._packed["layers"][0]
-    # Same operands as in the step: the GEMM reads the bf16 output of the LayerNorm kernel that runs
-    # right before it (so its A operand is as cache-warm as in the encoder) and the block-0 weights.
-    x = torch.zeros((rows, g.d_model), dtype=torch.float32, device=dev)
-    x[:hidden.numel() // g.d_model] = hidden.reshape(-1, g.d_model)
-    a = torch.empty((rows, g.d_model), dtype=torch.bfloat16, device=dev)
-    w, bias = lw["ffn1_w1"], lw["ffn1_b1"]
-    c = torch.empty((rows, g.ffn_dim), dtype=torch.bfloat16, device=dev)
+    fp8 = engine.fp8
+    peak = MFMA_FP8_PEAK_TFLOPS if fp8 else MFMA_BF16_PEAK_TFLOPS
+    d, f = g.d_model, g.ffn_dim
+    x = torch.zeros((rows, d), dtype=torch.float32, device=dev)
+    x[:hidden.numel() // d] = hidden.reshape(-1, d)
     st = _hip.current_stream_ptr()
-    iters = 20
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters + 1)]
-    for e0, e1 in ev:
-        _hip.check(L.oasr_layernorm(x.data_ptr(), lw["ffn1_ln_w"].data_ptr(), lw["ffn1_ln_b"].data_ptr(),
-                                    a.data_ptr(), rows, g.d_model, g.d_model, 1e-5, 1, 0, st))
-        e0.record()
-        _hip.check(L.oasr_gemm_bf16(a.data_ptr(), w.data_ptr(), bias.data_ptr(), None, c.data_ptr(), rows,
-                                    g.ffn_dim, g.d_model, 1.0, _hip.EPI_BIAS_SWISH_BF16, st))
-        e1.record()
-    torch.cuda.synchronize()
-    ms = sum(e0.elapsed_time(e1) for e0, e1 in ev[1:]) / iters
-    flops = 2.0 * rows * g.ffn_dim * g.d_model
-    tf = flops / (ms * 1e-3) / 1e12
+    bf = lambda r, c: torch.empty((r, c), dtype=torch.bfloat16, device=dev)
+    xn, big, ctx = bf(rows, d), bf(rows, max(f, 3 * d)), bf(rows, d)
+    a8 = torch.empty((rows, max(f, d)), dtype=torch.uint8, device=dev) if fp8 else None
+    sa = torch.empty((rows,), dtype=torch.float32, device=dev) if fp8 else None
+    resid = torch.zeros((rows, d), dtype=torch.float32, device=dev)
+    lengths = torch.full((batch,), min(t_pad, int(_hip.num_stacked(pcm.shape[1]))), dtype=torch.int32, device=dev)
+
+    def ln():          # LayerNorm -> A operand of the up-projection (bf16 rows, or e4m3 rows + scales)
+        if fp8:
+            _hip.check(L.oasr_layernorm_fp8(x.data_ptr(), lw["ffn1_ln_w"].data_ptr(), lw["ffn1_ln_b"].data_ptr(),
+                                            a8.data_ptr(), sa.data_ptr(), rows, d, 1e-5, 0, st))
+        else:
+            _hip.check(L.oasr_layernorm(x.data_ptr(), lw["ffn1_ln_w"].data_ptr(), lw["ffn1_ln_b"].data_ptr(),
+                                        xn.data_ptr(), rows, d, d, 1e-5, 1, 0, st))
+
+    def gemm(a, wname, bias, res, c, n, k, alpha, epi, quant=True):
+        def run():
+            if fp8:
+                _hip.check(L.oasr_gemm_fp8(a8.data_ptr(), lw[wname + "_q"].data_ptr(), sa.data_ptr(),
+                                           lw[wname + "_s"].data_ptr(), bias, res, c.data_ptr(), rows, n, k, alpha, epi, st))
+            else:
+                _hip.check(L.oasr_gemm_bf16(a.data_ptr(), lw[wname].data_ptr(), bias, res, c.data_ptr(), rows, n, k,
+                                            alpha, epi, st))
+        return run
+
+    def quant(a, k):   # fp8: the row quantiser that feeds a projection whose input a GEMM / attention produced
+        def run():
+            if fp8:
+                _hip.check(L.oasr_quant_fp8_rows(a.data_ptr(), rows, k, a8.data_ptr(), sa.data_ptr(), st))
+        return run
+
+    def entry(name, ms, flops, shape):
+        tf = flops / (ms * 1e-3) / 1e12
+        return {"kernel": name + " " + shape, "bound": "mfma", "achieved": round(tf, 1), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(tf / peak, 4), "flop_per_launch": flops, "avg_launch_ms": round(ms, 4)}
+
+    kern = "gemm_fp8_kernel" if fp8 else "gemm_bf16_kernel"
+    up = gemm(xn, "ffn1_w1", lw["ffn1_b1"].data_ptr(), None, big, f, d, 1.0, _hip.EPI_BIAS_SWISH_BF16)
+    ms_up = _time_launches(ln, up)
+    down = gemm(big, "ffn1_w2", lw["ffn1_b2"].data_ptr(), resid.data_ptr(), resid, d, f, 0.5, _hip.EPI_RESIDUAL_F32)
+    ms_down = _time_launches(lambda: (ln(), up(), quant(big, f)()), down)
+    qkv = gemm(xn, "wqkv", lw["bqkv"].data_ptr(), None, big, 3 * d, d, 1.0, _hip.EPI_BIAS_BF16)
+    ln(); qkv()
+
+    def attn():
+        _hip.check(L.oasr_attention_relkey(big.data_ptr(), lw["dist_emb"].data_ptr(), lengths.data_ptr(), ctx.data_ptr(),
+                                           batch, t_pad, g.n_heads, g.head_dim, g.left_max, g.right_max, st))
+    ms_attn = _time_launches(None, attn)
+    wo = gemm(ctx, "wo", lw["bo"].data_ptr(), resid.data_ptr(), resid, d, d, 1.0, _hip.EPI_RESIDUAL_F32)
+    ms_wo = _time_launches(lambda: (attn(), quant(ctx, d)()), wo)
+    t_valid = int(lengths[0])
+    attn_flops = batch * (4.0 * t_valid * t_valid * d + 2.0 * t_valid * g.n_dist * d)
+
     buf = engine._get_buffers(batch, pcm.shape[1])
 
     def logmel():
@@ -112,51 +168,77 @@ def kernel_rooflines(engine, batch: int, t_pad: int, pcm, nv, hidden) -> dict:
                                      engine._tables.data_ptr(), buf["logmel"].data_ptr(),
                                      buf["stats"].data_ptr(), st))
 
-    ms_l = time_events(logmel, 20)
+    ms_l = _time_launches(None, logmel)
     frames = _hip.num_frames(pcm.shape[1])
     lm_bytes = batch * (pcm.shape[1] * 4.0 + frames * 80 * 4.0)
     gbs = lm_bytes / (ms_l * 1e-3) / 1e9
-    gemm_shape = "%dx%dx%d" % (rows, g.ffn_dim, g.d_model)
+    up_shape = "%dx%dx%d" % (rows, f, d)
     lm_shape = "%dx%d" % (batch, pcm.shape[1])
+    main = entry(kern + "<BIAS_SWISH>", ms_up, 2.0 * rows * f * d, up_shape)
+    main["traffic"] = measured_traffic("gemm_bf16_kernel<1>", up_shape) if not fp8 else None
+    attn_e = entry("attention_relkey_kernel<%d>" % g.head_dim, ms_attn, attn_flops,
+                   "%dx%dx%dx%d" % (batch, g.n_heads, t_valid, g.head_dim))
+    attn_e["peak"], attn_e["frac"] = MFMA_BF16_PEAK_TFLOPS, round(attn_e["achieved"] / MFMA_BF16_PEAK_TFLOPS, 4)
     return {
-        "roofline": {"kernel": "gemm_bf16_kernel<BIAS_SWISH> " + gemm_shape,
-                     "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
-                     "traffic": measured_traffic("gemm_bf16_kernel<1>", gemm_shape),
-                     "flop_per_launch": flops, "avg_launch_ms": round(ms, 4)},
-        "roofline_logmel": {"kernel": "logmel_kernel " + lm_shape, "bound": "hbm", "achieved": round(gbs, 1),
-                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                            "traffic": measured_traffic("logmel_kernel", lm_shape),
-                            "bytes_per_launch": lm_bytes, "avg_launch_ms": round(ms_l, 4)},
+        "roofline": main,
+        "roofline_more": {
+            "ffn_down": entry(kern + "<RESIDUAL_F32>", ms_down, 2.0 * rows * d * f, "%dx%dx%d" % (rows, d, f)),
+            "dxd_residual": entry(kern + "<RESIDUAL_F32>", ms_wo, 2.0 * rows * d * d, "%dx%dx%d" % (rows, d, d)),
+            "attention": attn_e,
+            "logmel": {"kernel": "logmel_kernel " + lm_shape, "bound": "hbm", "achieved": round(gbs, 1),
+                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                       "traffic": measured_traffic("logmel_kernel", lm_shape),
+                       "bytes_per_launch": lm_bytes, "avg_launch_ms": round(ms_l, 4)},
+        },
     }
 
 
-def cpu_baseline(seconds: float, seed: int, utterances: int = 4, runs: int = 3) -> dict:
-    """The CPU oracle (float32 PyTorch restatement of the same geometry) on this host's cores, on a
-    bounded sample of the same synthetic workload: the first `utterances` rows of the batch, one
-    warm-up on a single utterance, then the median of `runs` timed passes."""
-    from omnilingual_asr.weights import GEOMETRIES, init_random_weights
+# Tolerances of the parity tests (tests/test_gpu_encoder.py, tests/test_gpu_fp8.py): per utterance, relative
+# L2 and largest absolute difference of the encoder states against the CPU oracle.
+PARITY_TOL = {"bf16": (2e-2, 0.15), "fp8": (3e-2, None)}     # the fp8 test states no absolute bound
+
+
+def cpu_baseline(engine, weights, pcm_rows: np.ndarray, seconds: float, hip_hidden, n_layers: int, runs: int) -> dict:
+    """The CPU oracle (float32 PyTorch restatement of the same geometry; with --fp8 its emulation of the
+    device's quantisation) on this host's cores, on a bounded sample of the benchmarked batch: the rows
+    `pcm_rows` copied back from the device tensor the step ran on, through the first `n_layers` blocks.
+    One warm-up on a single row, then the median of `runs` timed passes.  The oracle's output is then
+    compared with the device's states for the same rows and depth (`hip_hidden`)."""
     from oracle import conformer as OC
     from oracle import logmel as OL
 
-    g = GEOMETRIES["G300"]
-    w = init_random_weights(g, 0)
-    pcm = synth_batch(utterances, int(seconds * 16000), seed).numpy()
+    g = engine.geometry
+    og = OC.Geometry(name=g.name, d_model=g.d_model, ffn_dim=g.ffn_dim, n_heads=g.n_heads, n_layers=n_layers)
+    w = dict(weights)
+    w["layers"] = weights["layers"][:n_layers]
     threads = torch.get_num_threads()
+    out = {}
 
     def one_pass(x):
         t0 = time.perf_counter()
         feats, lens = OL.features_batch(x, None)
-        OC.forward(torch.from_numpy(feats), torch.from_numpy(lens), w, OC.G300)
+        out["hidden"] = OC.forward(torch.from_numpy(feats), torch.from_numpy(lens), w, og, fp8=engine.fp8)
+        out["lens"] = lens
         return time.perf_counter() - t0
 
-    one_pass(pcm[:1])
-    times = sorted(one_pass(pcm) for _ in range(runs))
-    dt = times[len(times) // 2]
-    return {"value": round(utterances * seconds / dt, 3), "unit": "x real time (audio-s/wall-s)",
+    if runs > 1:
+        one_pass(pcm_rows[:1, : pcm_rows.shape[1] // 4])
+    times = sorted(one_pass(pcm_rows) for _ in range(runs))
+    dt = times[len(times) // 2] * (g.n_layers / float(n_layers))      # scaled to the full depth
+    want, lens = out["hidden"], out["lens"]
+    rel = mx = 0.0
+    for i in range(pcm_rows.shape[0]):
+        a, b = hip_hidden[i, : lens[i]].double(), want[i, : lens[i]].double()
+        rel = max(rel, float((a - b).norm() / b.norm()))
+        mx = max(mx, float((a - b).abs().max()))
+    tol = PARITY_TOL["fp8" if engine.fp8 else "bf16"]
+    depth = "all %d blocks" % n_layers if n_layers == g.n_layers else         "the first %d of %d blocks, time scaled by %d/%d" % (n_layers, g.n_layers, g.n_layers, n_layers)
+    return {"value": round(pcm_rows.shape[0] * seconds / dt, 3), "unit": "x real time (audio-s/wall-s)",
             "cores": threads, "kind": "port",
-            "sample": "%d x %.0f s utterances of the batch, float32 oracle (log-mel + 12 blocks), median of %d "
-                      "passes = %.1f s wall, total %.1f s" % (utterances, seconds, runs, dt, sum(times))}
+            "sample": "rows 0..%d of the benchmarked batch (%.0f s each), float32 oracle (log-mel + %s), median of %d "
+                      "pass(es), %.1f s of CPU work in all" % (pcm_rows.shape[0] - 1, seconds, depth, runs, sum(times)),
+            "parity": {"rows": int(pcm_rows.shape[0]), "blocks": n_layers, "rel_l2": round(rel, 5), "max_abs": round(mx, 4),
+                       "tol_rel_l2": tol[0], "tol_max_abs": tol[1], "ok": bool(rel <= tol[0] and (tol[1] is None or mx <= tol[1]))}}
 
 
 def run_long_audio(args, world: int, rank: int) -> None:
@@ -274,7 +356,9 @@ def main() -> None:
     from omnilingual_asr.models.inference.asr_pipeline import ChunkRecord
     from omnilingual_asr import _hip
 
-    engine = HipEngine(args.model, seed=0, fp8=args.fp8)
+    from omnilingual_asr.weights import init_random_weights, resolve_geometry
+    weights = init_random_weights(resolve_geometry(args.model), 0)
+    engine = HipEngine(args.model, weights=weights, fp8=args.fp8)
     g = engine.geometry
     n = int(args.seconds * 16000)
     dev = engine.device
@@ -341,11 +425,28 @@ def main() -> None:
                                        (MFMA_FP8_PEAK_TFLOPS if args.fp8 else MFMA_BF16_PEAK_TFLOPS), 4),
             "encoder_mfma_peak": MFMA_FP8_PEAK_TFLOPS if args.fp8 else MFMA_BF16_PEAK_TFLOPS,
         }
+        # kernel timings first: the device is still at its working clocks right after the timed steps
         if not args.no_kernel_timing:
             line.update(kernel_rooflines(engine, args.batch, pad_frames(t_frames), pcm, nv, hidden))
+        parity_ok = True
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.seconds, 1234)
+            # bounded CPU sample: G300 = 4 rows at full depth; wider models = 1 row through 2 blocks
+            small = g.d_model <= 1024
+            n_rows, depth, runs = (min(4, args.batch), g.n_layers, 3) if small else (1, min(2, g.n_layers), 1)
+            if depth == g.n_layers:
+                hip_rows = hidden[:n_rows].float().cpu()          # the states the timed steps produced
+            else:
+                feats, lens_d = engine.features(pcm, nv)
+                hip_rows = engine.encode_features(feats, lens_d, depth)[:n_rows].float().cpu()
+            line["cpu_baseline"] = cpu_baseline(engine, weights, pcm[:n_rows].cpu().numpy(), args.seconds, hip_rows,
+                                                depth, runs)
+            parity_ok = line["cpu_baseline"]["parity"]["ok"]
         print(json.dumps(line), flush=True)
+        if not parity_ok:
+            print("bench.py: device states differ from the CPU oracle beyond the test tolerance", file=sys.stderr)
+            if world > 1:
+                dist.destroy_process_group()
+            raise SystemExit(3)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

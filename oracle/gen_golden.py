@@ -264,7 +264,7 @@ def part_a() -> dict:
 # ----------------------------------------------------------------------------------------------------
 # Part B
 
-def part_b() -> dict:
+def part_b(only_device_fixture: bool = False) -> dict:
     import torch
     from transformers import SeamlessM4TFeatureExtractor, Wav2Vec2BertConfig, Wav2Vec2BertModel
 
@@ -273,26 +273,27 @@ def part_b() -> dict:
     from oracle import logmel as OL
 
     info = {}
-    fe = SeamlessM4TFeatureExtractor()
-    rng = np.random.default_rng(0)
-    waves = {"noise_1s": (0.1 * rng.standard_normal(16000)).astype(np.float32),
-             "tone_odd": (0.3 * np.sin(2 * np.pi * 523.25 * np.arange(16400) / 16000.0)
-                          + 0.01 * rng.standard_normal(16400)).astype(np.float32)}
-    store = {}
-    for name, wav in waves.items():
-        enc = fe(wav, sampling_rate=16000, return_tensors="np")
-        feats, mask = enc["input_features"][0], enc["attention_mask"][0]
-        raw = fe._extract_fbank_features(wav)
-        store[name + "_pcm"] = wav
-        store[name + "_logmel"] = raw.astype(np.float32)
-        store[name + "_features"] = feats.astype(np.float32)
-        store[name + "_mask"] = mask.astype(np.int32)
-        mine = OL.features(wav)
-        n = int(mask.sum())
-        info[name] = {"frames": int(raw.shape[0]), "valid_stacked": n,
-                      "max_abs_diff_logmel": float(np.abs(OL.logmel(wav) - raw).max()),
-                      "max_abs_diff_features": float(np.abs(mine[:n] - feats[:n]).max())}
-    np.savez_compressed(GOLDEN / "standin_logmel.npz", **store)
+    if not only_device_fixture:
+        fe = SeamlessM4TFeatureExtractor()
+        rng = np.random.default_rng(0)
+        waves = {"noise_1s": (0.1 * rng.standard_normal(16000)).astype(np.float32),
+                 "tone_odd": (0.3 * np.sin(2 * np.pi * 523.25 * np.arange(16400) / 16000.0)
+                              + 0.01 * rng.standard_normal(16400)).astype(np.float32)}
+        store = {}
+        for name, wav in waves.items():
+            enc = fe(wav, sampling_rate=16000, return_tensors="np")
+            feats, mask = enc["input_features"][0], enc["attention_mask"][0]
+            raw = fe._extract_fbank_features(wav)
+            store[name + "_pcm"] = wav
+            store[name + "_logmel"] = raw.astype(np.float32)
+            store[name + "_features"] = feats.astype(np.float32)
+            store[name + "_mask"] = mask.astype(np.int32)
+            mine = OL.features(wav)
+            n = int(mask.sum())
+            info[name] = {"frames": int(raw.shape[0]), "valid_stacked": n,
+                          "max_abs_diff_logmel": float(np.abs(OL.logmel(wav) - raw).max()),
+                          "max_abs_diff_features": float(np.abs(mine[:n] - feats[:n]).max())}
+        np.savez_compressed(GOLDEN / "standin_logmel.npz", **store)
 
     def convert(model, n_layers):
         sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
@@ -319,7 +320,7 @@ def part_b() -> dict:
             w["layers"].append({k: L[k] for k in OC.LAYER_KEYS})
         return w
 
-    def run(hidden, heads, inter, layers, t, lengths, seed, keep):
+    def run(hidden, heads, inter, layers, t, lengths, seed, keep, bf16_matrices=False):
         cfg = Wav2Vec2BertConfig(hidden_size=hidden, num_attention_heads=heads, intermediate_size=inter,
                                  num_hidden_layers=layers)
         torch.manual_seed(seed)
@@ -330,6 +331,13 @@ def part_b() -> dict:
                     p_.add_(0.1 * torch.randn_like(p_))
                 elif n_.endswith(".bias"):
                     p_.add_(0.05 * torch.randn_like(p_))
+            if bf16_matrices:
+                # the device keeps projection matrices and the distance embedding in bf16: round them in
+                # the stand-in model itself, so its outputs belong to exactly the stored weights (the
+                # depthwise taps stay float32, as on the device)
+                for n_, p_ in model.named_parameters():
+                    if p_.dim() >= 2 and "depthwise_conv" not in n_:
+                        p_.copy_(p_.to(torch.bfloat16).to(torch.float32))
         gen = torch.Generator().manual_seed(seed + 1)
         feats = torch.randn((len(lengths), t, 160), generator=gen)
         lens = torch.tensor(lengths, dtype=torch.int32)
@@ -346,18 +354,31 @@ def part_b() -> dict:
                 d = max(d, float((per[k][b, :n] - o.hidden_states[k][b, :n]).abs().max()))
             diffs.append(d)
         if keep:
+            target = keep if isinstance(keep, str) else "standin_encoder.npz"
             flat = {"feats": feats.numpy(), "lengths": lens.numpy()}
             for k, h in enumerate(o.hidden_states):
                 flat[f"hidden_{k}"] = h.numpy()
+            def put(name, val):
+                if bf16_matrices and val.dim() >= 2 and not name.endswith(".dw"):
+                    # exact: the values are bf16 already; stored as their 16-bit patterns
+                    flat[name + ":bf16"] = val.to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+                else:
+                    flat[name] = val.numpy()
             for key, val in w.items():
                 if key != "layers":
-                    flat["w." + key] = val.numpy()
+                    put("w." + key, val)
             for i, L in enumerate(w["layers"]):
                 for key, val in L.items():
-                    flat[f"w.layers.{i}.{key}"] = val.numpy()
+                    put(f"w.layers.{i}.{key}", val)
             flat["geometry"] = np.array([hidden, inter, heads, layers], dtype=np.int32)
-            np.savez_compressed(GOLDEN / "standin_encoder.npz", **flat)
+            np.savez_compressed(GOLDEN / target, **flat)
         return diffs
+
+    if only_device_fixture:
+        return {"encoder_device_width": {
+            "config": "hidden 512, 8 heads, ffn 256, 2 blocks, T=104, lengths [104, 77, 1]; matrices rounded to "
+                      "bf16 inside the stand-in model and stored as bf16 (standin_encoder_d512.npz)",
+            "max_abs_diff_per_layer": run(512, 8, 256, 2, 104, [104, 77, 1], 2, "standin_encoder_d512.npz", True)}}
 
     info["encoder_small"] = {"config": "hidden 128, 2 heads, ffn 256, 2 blocks, T=101, lengths [101, 77]",
                              "max_abs_diff_per_layer": run(128, 2, 256, 2, 101, [101, 77], 0, True)}
@@ -369,6 +390,15 @@ def part_b() -> dict:
 
 def main():
     GOLDEN.mkdir(parents=True, exist_ok=True)
+    if "--device-fixture" in sys.argv:
+        # only the stand-in encoder fixture at a width the device kernels accept; merges its entry into
+        # standin_info.json and leaves every other fixture as it is
+        info_path = GOLDEN / "standin_info.json"
+        info = json.loads(info_path.read_text())
+        info.update(part_b(only_device_fixture=True))
+        info_path.write_text(json.dumps(info, indent=1, sort_keys=True) + "\n")
+        print(json.dumps(info["encoder_device_width"], indent=1))
+        return
     a = part_a()
     (GOLDEN / "reference_host.json").write_text(json.dumps(a, indent=1, sort_keys=True) + "\n")
     # the reference's own sample file, used by the plumbing tests (BASELINE config 1)

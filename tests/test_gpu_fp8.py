@@ -175,3 +175,41 @@ def test_encoder_fp8_matches_fake_quant_oracle():
         assert rel(h8[i, :n], ref16[i, :n]) <= 1.5e-1           # stated fp8 tolerance vs the float32 oracle
         assert rel(h8[i, :n], h16[i, :n]) > 5e-3               # and not the bf16 path
     assert torch.isfinite(h8).all()
+
+
+def test_encoder_block_at_the_7b_width_bf16_and_fp8():
+    """One block of the 7B geometry (d = 4096, ffn 16384, 32 heads x 128) on a short ragged batch, so the
+    CPU oracle stays cheap: bf16 against the float32 oracle (rel-L2 <= 2e-2, max abs <= 0.15) and fp8
+    against the oracle emulating the same quantisation (rel-L2 <= 3e-2; <= 1.5e-1 against float32).  At
+    this width the convolution module runs its unfused form (convolution -> float32 rows -> LayerNorm +
+    Swish), which this test is the cover for."""
+    import dataclasses
+    from omnilingual_asr.engine_hip import HipEngine
+    from omnilingual_asr.weights import GEOMETRIES, init_random_weights
+    from oracle import conformer as OC
+    from oracle import logmel as OL
+    from tests.test_gpu_ops import synth_pcm
+
+    g = dataclasses.replace(GEOMETRIES["G7B"], n_layers=1)
+    assert (g.d_model, g.ffn_dim, g.n_heads, g.head_dim) == (4096, 16384, 32, 128)
+    og = OC.Geometry(name=g.name, d_model=g.d_model, ffn_dim=g.ffn_dim, n_heads=g.n_heads, n_layers=1)
+    w = init_random_weights(g, 31)
+    pcm = synth_pcm(2, 64000, seed=6)
+    n_valid = [64000, 41000]
+    feats, lens = OL.features_batch(pcm.numpy(), n_valid)
+    enc_w = {k: v for k, v in w.items() if not k.startswith("ctc_")}
+    ft, lt = torch.from_numpy(feats), torch.from_numpy(lens)
+    ref16 = OC.forward(ft, lt, enc_w, og)
+    ref8 = OC.forward(ft, lt, enc_w, og, fp8=True)
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    h16, l16 = HipEngine(g, weights=w).encode_batch(pcm, n_valid)
+    h16 = h16.cpu()
+    h8 = HipEngine(g, weights=w, fp8=True).encode_batch(pcm, n_valid)[0].cpu()
+    assert torch.isfinite(h16).all() and torch.isfinite(h8).all()
+    for i, n in enumerate(lens):
+        assert int(l16[i]) == int(n)
+        assert rel(h16[i, :n], ref16[i, :n]) <= 2e-2
+        assert float((h16[i, :n] - ref16[i, :n]).abs().max()) <= 0.15
+        assert rel(h8[i, :n], ref8[i, :n]) <= 3e-2
+        assert rel(h8[i, :n], ref16[i, :n]) <= 1.5e-1
+        assert rel(h8[i, :n], h16[i, :n]) > 5e-3

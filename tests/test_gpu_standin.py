@@ -1,0 +1,82 @@
+"""The HIP kernels against the committed vectors of the independent third-party implementation
+(transformers' SeamlessM4T feature extractor / Wav2Vec2-BERT encoder with seeded random weights, made by
+oracle/gen_golden.py part B) with no oracle in between.  The reference contains neither stage, so this
+is a cross-check of the declared geometry, not reference parity; it closes the chain
+device <-> oracle <-> stand-in that the other tests establish only link by link."""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def load_standin_weights(z):
+    """Weight dict of `omnilingual_asr.weights` layout from a stand-in fixture (matrices may be stored as
+    bf16 bit patterns under '<name>:bf16')."""
+    def get(name):
+        if name + ":bf16" in z.files:
+            return torch.from_numpy(z[name + ":bf16"].view(np.int16).copy()).view(torch.bfloat16).to(torch.float32)
+        return torch.from_numpy(z[name])
+
+    names = sorted({k.split(":")[0] for k in z.files if k.startswith("w.")})
+    layers = int(z["geometry"][3])
+    w = {n[2:]: get(n) for n in names if not n.startswith("w.layers.")}
+    w["layers"] = []
+    for i in range(layers):
+        pre = f"w.layers.{i}."
+        w["layers"].append({n[len(pre):]: get(n) for n in names if n.startswith(pre)})
+    return w
+
+
+@pytest.mark.parametrize("name", ["noise_1s", "tone_odd"])
+def test_logmel_kernels_match_the_standin_vectors(golden_dir, name):
+    """PCM of the fixture through oasr_logmel_f32 + oasr_feature_norm_stack; tolerances of the device
+    feature tests: log-mel 2e-3, normalised stacked features 5e-3 (absolute)."""
+    from omnilingual_asr.engine_hip import HipEngine
+
+    z = np.load(golden_dir / "standin_logmel.npz")
+    pcm = z[name + "_pcm"]
+    raw, feats, mask = z[name + "_logmel"], z[name + "_features"], z[name + "_mask"]
+    n = int(mask.sum())
+    eng = HipEngine("GTINY", seed=0)
+    width = (len(pcm) + 3) // 4 * 4
+    x = torch.zeros((1, width), dtype=torch.float32, device="cuda")
+    x[0, : len(pcm)] = torch.from_numpy(pcm).cuda()
+    nv = torch.tensor([len(pcm)], dtype=torch.int32, device="cuda")
+    buf = eng._get_buffers(1, width)
+    got_feats, lengths = eng.features(x, nv, buf)
+    torch.cuda.synchronize()
+    assert int(lengths[0]) == n
+    np.testing.assert_allclose(buf["logmel"][0, : raw.shape[0]].cpu().numpy(), raw, atol=2e-3)
+    np.testing.assert_allclose(got_feats[0, :n].cpu().numpy(), feats[:n], atol=5e-3)
+    assert float(got_feats[0, n:].abs().max()) == 0.0
+
+
+def test_encoder_matches_the_standin_hidden_states(golden_dir):
+    """Stand-in encoder at a width the kernels accept (d = 512, 8 heads of 64, ffn 256, 2 blocks, ragged
+    batch with a one-frame utterance): device states after the input projection, one block and two blocks
+    against the stand-in's own hidden states.  Weights are bf16-exact in the fixture, so what differs is
+    the device arithmetic only: relative L2 <= 2e-2 and 0.15 absolute, as in the oracle comparisons."""
+    from omnilingual_asr.engine_hip import HipEngine, pad_frames
+    from omnilingual_asr.weights import Geometry
+
+    z = np.load(golden_dir / "standin_encoder_d512.npz")
+    hidden, inter, heads, layers = [int(v) for v in z["geometry"]]
+    assert (hidden, inter, heads, layers) == (512, 256, 8, 2)
+    w = load_standin_weights(z)
+    g = Geometry(name="standin", d_model=hidden, ffn_dim=inter, n_heads=heads, n_layers=layers)
+    eng = HipEngine(g, weights=w)
+    feats, lens = z["feats"], z["lengths"]
+    b, t, _ = feats.shape
+    t_pad = pad_frames(t)
+    fd = torch.zeros((b, t_pad, 160), dtype=torch.float32, device="cuda")
+    fd[:, :t] = torch.from_numpy(feats).cuda()
+    ld = torch.from_numpy(lens).to(torch.int32).cuda()
+    for k in range(layers + 1):
+        got = eng.encode_features(fd, ld, k).float().cpu()
+        want = torch.from_numpy(z[f"hidden_{k}"])
+        for i, n in enumerate(lens.tolist()):
+            a, r = got[i, :n], want[i, :n]
+            assert float((a - r).norm() / r.norm()) <= 2e-2, (k, i)
+            assert float((a - r).abs().max()) <= 0.15, (k, i)

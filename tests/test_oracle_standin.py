@@ -77,3 +77,20 @@ def test_float64_and_float32_oracles_agree(golden_dir):
     a = OC.forward(feats, lens, w, g, dtype=torch.float32)
     b = OC.forward(feats, lens, w, g, dtype=torch.float64).float()
     torch.testing.assert_close(a[0], b[0], atol=5e-5, rtol=1e-4)
+
+
+def test_encoder_matches_standin_at_the_device_width(golden_dir):
+    """The fixture the device test uses (d = 512, matrices bf16-exact): the float32 oracle agrees with the
+    stand-in's hidden states per layer."""
+    from tests.test_gpu_standin import load_standin_weights
+
+    z = np.load(golden_dir / "standin_encoder_d512.npz")
+    hidden, inter, heads, layers = [int(v) for v in z["geometry"]]
+    w = load_standin_weights(z)
+    g = OC.Geometry(name="standin", d_model=hidden, ffn_dim=inter, n_heads=heads, n_layers=layers)
+    feats, lens = torch.from_numpy(z["feats"]), torch.from_numpy(z["lengths"])
+    _, per = OC.forward(feats, lens, w, g, per_layer=True)
+    for k in range(layers + 1):
+        want = torch.from_numpy(z[f"hidden_{k}"])
+        for b, n in enumerate(lens.tolist()):
+            torch.testing.assert_close(per[k][b, :n], want[b, :n], atol=2e-5, rtol=1e-5)
