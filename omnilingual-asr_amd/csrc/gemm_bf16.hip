@@ -218,7 +218,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][4],
     }
 }
 
-template <int EPI>
+// LONGK only names the instantiation (K >= 2048 or not): the code is the same, but profilers then list
+// the K = 4096 down-projection and the K = 1024 projections that share an epilogue as separate kernels.
+template <int EPI, bool LONGK>
 __global__ __launch_bounds__(512) void gemm_bf16_kernel(const uint16_t* __restrict__ A,
                                                         const uint16_t* __restrict__ W,
                                                         const float* __restrict__ bias,
@@ -516,8 +518,13 @@ extern "C" int oasr_gemm_bf16(const uint16_t* a, const uint16_t* w, const float*
     // number of work-groups
     dim3 grid((unsigned)(tiles < kMaxCUs ? (tiles + 7) / 8 * 8 : kMaxCUs)), blk(512);
     hipStream_t st = (hipStream_t)stream;
-#define OASR_LAUNCH_GEMM(E) \
-    hipLaunchKernelGGL((gemm_bf16_kernel<E>), grid, blk, 0, st, a, w, bias, resid, c, n, k, alpha, tiles)
+#define OASR_LAUNCH_GEMM(E)                                                                                          \
+    do {                                                                                                             \
+        if (k >= 2048)                                                                                               \
+            hipLaunchKernelGGL((gemm_bf16_kernel<E, true>), grid, blk, 0, st, a, w, bias, resid, c, n, k, alpha, tiles);  \
+        else                                                                                                         \
+            hipLaunchKernelGGL((gemm_bf16_kernel<E, false>), grid, blk, 0, st, a, w, bias, resid, c, n, k, alpha, tiles); \
+    } while (0)
     switch (epilogue) {
         case OASR_EPI_BIAS_BF16: OASR_LAUNCH_GEMM(OASR_EPI_BIAS_BF16); break;
         case OASR_EPI_BIAS_SWISH_BF16: OASR_LAUNCH_GEMM(OASR_EPI_BIAS_SWISH_BF16); break;

@@ -235,3 +235,51 @@ def test_four_threads_share_one_pipeline(tmp_path):
         with ThreadPoolExecutor(max_workers=4) as ex:
             got = list(ex.map(lambda p: key(pipe.transcribe(p, word_timestamps=True)), paths))
         assert got == want
+
+
+def test_http_shell_on_the_hip_engine(tmp_path, golden_dir):
+    """The server of ref:workflows/wav2elan_web/app.py's contract with the default (HIP) engine behind it:
+    single upload, event stream with the four progress steps, and a batch of four files transcribed
+    concurrently on the one shared pipeline (ref app.py:383-399) — results equal the direct call."""
+    import io
+    import json
+    import zipfile
+    starlette_testclient = pytest.importorskip("starlette.testclient")
+    from omnilingual_asr import Pipeline
+    from omnilingual_asr.server import create_app
+
+    pipe = Pipeline(model="GTINY", seed=4)
+    want = pipe.transcribe(str(golden_dir / "gettysburg.wav"), word_timestamps=True)
+    client = starlette_testclient.TestClient(create_app(pipe, upload_dir=tmp_path / "uploads"))
+    wav = (golden_dir / "gettysburg.wav").read_bytes()
+    entry = client.post("/api/transcribe", files={"file": ("gettysburg.wav", wav, "audio/wav")}).json()
+    seg = entry["segments"][0]
+    assert (seg["start"], seg["end"], seg["text"]) == (want[0].start, want[0].end, want[0].text)
+    assert [w["word"] for w in seg["words"]] == [w.word for w in want[0].words]
+
+    def events(text):
+        out = []
+        for block in text.replace("\r\n", "\n").strip().split("\n\n"):
+            lines = dict(l.split(": ", 1) for l in block.split("\n"))
+            out.append((lines["event"], json.loads(lines["data"])))
+        return out
+
+    r = client.post("/api/transcribe-stream", files={"file": ("g.wav", wav, "audio/wav")})
+    ev = events(r.text)
+    assert [(e, d["step"], d["index"]) for e, d in ev[:-1]] == \
+        [("progress", s, i) for s, i in (("uploading", 0), ("transcribing", 1), ("processing", 2), ("done", 3))]
+    assert ev[-1][1]["segments"][0]["text"] == want[0].text
+    long_wav = tmp_path / "long.wav"
+    _write_wav(long_wav, 70.0, seed=3)
+    want_long = pipe.transcribe(str(long_wav))
+    buf = io.BytesIO()
+    with zipfile.ZipFile(buf, "w") as zf:
+        zf.writestr("a/one.wav", wav)
+        zf.writestr("a/two.wav", long_wav.read_bytes())
+    r = client.post("/api/transcribe-batch-stream", files=[("files", ("pack.zip", buf.getvalue(), "application/zip")),
+                                                           ("files", ("three.wav", wav, "audio/wav")),
+                                                           ("files", ("four.wav", long_wav.read_bytes(), "audio/wav"))])
+    results = events(r.text)[-1][1]["results"]
+    assert [x["file_name"] for x in results] == ["a/one.wav", "a/two.wav", "three.wav", "four.wav"]
+    for x, ref in zip(results, (want, want_long, want, want_long)):
+        assert [(s["start"], s["end"], s["text"]) for s in x["segments"]] == [(s.start, s.end, s.text) for s in ref]
