@@ -66,10 +66,12 @@ def measured_traffic(kernel: str, shape: str):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE are collected in separate profiler runs, never inside this script); None when the file
     holds no entry for this kernel at this shape."""
-    path = ROOT / "profiles" / "r01_traffic.json"
-    if not path.exists():
-        return None
-    entry = json.loads(path.read_text()).get(kernel)
+    found = sorted((ROOT / "profiles").glob("r*_traffic.json"))      # the newest round that holds the kernel
+    entry = None
+    for path in reversed(found):
+        entry = json.loads(path.read_text()).get(kernel)
+        if entry:
+            break
     if not entry or entry.get("shape") != shape:
         return None
     return entry["traffic_bytes_per_launch"]

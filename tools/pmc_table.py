@@ -25,12 +25,14 @@ if md:
     print("|" + "---|" * (len(table) + 1))
 for k in names:
     print(("| " if md else "") + sep.join([k.ljust(28)] + [("%14.4g" % t[k]) if k in t else " " * 14 for t in table.values()]) + (" |" if md else ""))
-# derived: the matrix pipes of the chip offer 4 SIMDs x 256 CUs cycles per GRBM_GUI_ACTIVE cycle
+# derived: GRBM_GUI_ACTIVE is summed over the 8 XCDs, so the kernel ran for gui_active / 8 cycles, during
+# which the chip's 1024 SIMDs (4 x 256 CUs) each offered one matrix-pipe cycle per cycle
 derived = collections.OrderedDict()
 for n, t in table.items():
     d = {}
     if "SQ_VALU_MFMA_BUSY_CYCLES" in t and "GRBM_GUI_ACTIVE" in t:
-        d["mfma_busy / (gui_active * 1024 SIMDs)"] = t["SQ_VALU_MFMA_BUSY_CYCLES"] / (t["GRBM_GUI_ACTIVE"] * 1024.0)
+        d["MFMA util = mfma_busy/(gui_active/8*1024)"] = t["SQ_VALU_MFMA_BUSY_CYCLES"] / (t["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+        d["kernel cycles = gui_active / 8"] = t["GRBM_GUI_ACTIVE"] / 8.0
     if "SQ_VALU_MFMA_BUSY_CYCLES" in t and "SQ_BUSY_CU_CYCLES" in t:
         d["mfma_busy / (busy_cu_cycles * 4)"] = t["SQ_VALU_MFMA_BUSY_CYCLES"] / (t["SQ_BUSY_CU_CYCLES"] * 4.0)
     if "SQ_WAIT_ANY" in t and "SQ_WAVE_CYCLES" in t:
@@ -42,5 +44,8 @@ for n, t in table.items():
     derived[n] = d
 keys = sorted({k for d in derived.values() for k in d})
 print()
+if md:
+    print("| derived | " + " | ".join(n.rjust(14) for n in table) + " |")
+    print("|" + "---|" * (len(table) + 1))
 for k in keys:
-    print(("| " if md else "") + sep.join([k.ljust(40)] + [("%14.4f" % d[k]) if k in d else " " * 14 for d in derived.values()]) + (" |" if md else ""))
+    print(("| " if md else "") + sep.join([k.ljust(44)] + [("%14.4g" % d[k]) if k in d else " " * 14 for d in derived.values()]) + (" |" if md else ""))

@@ -51,15 +51,17 @@ for mode, cmd in (("graph", "python3 bench.py --steps 10 --warmup 3 --no-cpu-bas
         log = out / ("%s_stats_%s.log" % (tag, mode))
         last = [l for l in log.read_text().splitlines() if l.startswith("{")]
         md += ["## `rocprofv3 --kernel-trace --stats -- %s`" % cmd, "",
-               "13 forwards (3 warm-up + 10 timed) plus the 21 event-timed launches each of the FFN up-projection GEMM",
-               "and the log-mel kernel that bench.py issues for its roofline lines.", "", table, ""]
+               "13 forwards (3 warm-up + 10 timed) plus the event-timed launches (21 each) of the kernels bench.py reports",
+               "roofline lines for: the three GEMM shapes of a block with the kernels that feed them, attention, log-mel.",
+               "`gemm_bf16_kernel<E, L>`: E = epilogue (0 bias, 1 bias+Swish, 2 GLU, 3 float32 residual, 4 float32 bias),",
+               "L = true for K >= 2048 (the FFN down-projection), false for the K = 1024 projections.", "", table, ""]
         if last:
             md += ["bench line of this run:", "", "```", last[-1], "```", ""]
 
 traffic = {}
 KB = 1024.0
 for kind, substr, key, shape, algo in (
-        ("gemm", "gemm_bf16_kernel<1>", "gemm_bf16_kernel<1>", "48128x4096x1024",
+        ("gemm", "gemm_bf16_kernel<1", "gemm_bf16_kernel<1>", "48128x4096x1024",
          48128 * 1024 * 2 + 4096 * 1024 * 2 + 4096 * 4 + 48128 * 4096 * 2),
         ("logmel", "logmel_kernel", "logmel_kernel", "32x480000", 32 * (480000 * 4 + 2998 * 80 * 4))):
     fetch = counter(kind, "FETCH_SIZE", substr)
@@ -80,5 +82,18 @@ for k, v in traffic.items():
     md.append("| `%s` | %s | %.0f | %.0f | %.1f | %.1f |" % (k, v["shape"], v["FETCH_SIZE_KiB_raw"], v["WRITE_SIZE_KiB_raw"],
                                                           v["traffic_bytes_per_launch"] / 1e6,
                                                           v["algorithmic_bytes_per_launch"] / 1e6))
+# SQ / GRBM counter passes (tools/pmc_kernels.sh), when they were collected for this tag
+import subprocess
+pmc_dir = out / ("%s_pmc" % tag)
+if pmc_dir.exists():
+    table = subprocess.run([sys.executable, str(ROOT / "tools" / "pmc_table.py"), str(pmc_dir), "--md"],
+                           capture_output=True, text=True).stdout
+    (prof / ("%s_pmc.md" % tag)).write_text(
+        "# %s - SQ / GRBM counters per launch (`tools/pmc_kernels.sh`, one `rocprofv3 --pmc` run per pass and kernel)\n\n"
+        "Targets: ffn_up = `gemm_bf16_kernel<1, false>` 48128x4096x1024, ffn_down = `gemm_bf16_kernel<3, true>` 48128x1024x4096,\n"
+        "dxd_res = `gemm_bf16_kernel<3, false>` 48128x1024x1024, attn64 = `attention_relkey_kernel<64>` 32 x 16 heads x 1499.\n"
+        "Median over the launches of a run.  SQ_*_CYCLES of waves count quad-cycles; SQ_VALU_MFMA_BUSY_CYCLES and\n"
+        "GRBM_GUI_ACTIVE count cycles, GRBM_GUI_ACTIVE summed over the 8 XCDs; SQ_INSTS_VALU includes the MFMAs.\n\n" % tag + table)
+    md += ["## Matrix-pipe utilisation and stall counters", "", "See `%s_pmc.md`." % tag, ""]
 (prof / ("%s_summary.md" % tag)).write_text("\n".join(md) + "\n")
 print("\n".join(md))
