@@ -80,6 +80,40 @@ int build_logmel_blob(uint32_t* blob) {
     }
     b->mel_start[OASR_NMEL] = 0;
     b->mel_width_max = widest;
+    // MFMA form of the weights; every non-zero weight must fall into one of the listed tasks
+    auto to_bf16 = [](float f) {
+        uint32_t u;
+        memcpy(&u, &f, 4);
+        u += 0x7FFFu + ((u >> 16) & 1u);
+        return (uint16_t)(u >> 16);
+    };
+    auto from_bf16 = [](uint16_t h) {
+        uint32_t u = (uint32_t)h << 16;
+        float f;
+        memcpy(&f, &u, 4);
+        return f;
+    };
+    std::vector<char> covered((size_t)nb * OASR_NMEL, 0);
+    for (int t = 0; t < kMelTasks; ++t)
+        for (int l = 0; l < 64; ++l)
+            for (int d = 0; d < 4; ++d) {
+                uint32_t hi = 0, lo = 0;
+                for (int h = 0; h < 2; ++h) {
+                    const int sigma = 8 * (l >> 4) + 2 * d + h;
+                    const int bin = 32 * kMelTaskStep[t] + (sigma >> 1) + 16 * (sigma & 1);
+                    const int filt = 16 * kMelTaskBlock[t] + (l & 15);
+                    const float w = (float)dense[(size_t)bin * OASR_NMEL + filt];
+                    covered[(size_t)bin * OASR_NMEL + filt] = 1;
+                    const uint16_t wh = to_bf16(w), wl = to_bf16(w - from_bf16(wh));
+                    hi |= (uint32_t)wh << (16 * h);
+                    lo |= (uint32_t)wl << (16 * h);
+                }
+                b->mel_frag[t][0][l][d] = hi;
+                b->mel_frag[t][1][l][d] = lo;
+            }
+    for (int k = 0; k < nb; ++k)
+        for (int j = 0; j < OASR_NMEL; ++j)
+            if (dense[(size_t)k * OASR_NMEL + j] > 0.0 && !covered[(size_t)k * OASR_NMEL + j]) return -1;
     return 0;
 }
 

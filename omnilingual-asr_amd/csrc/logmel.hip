@@ -1,12 +1,25 @@
 // Log-mel feature extraction for gfx950: framing, DC removal, pre-emphasis, Povey window,
-// 512-point real FFT (as a 256-point complex radix-4 FFT held across one wavefront), power,
-// sparse mel triangles, log; then per-utterance per-bin normalisation and frame-pair stacking.
+// 512-point real FFT, power, mel triangles, log; then per-utterance per-bin normalisation and
+// frame-pair stacking.
 //
-// Work decomposition: one 256-thread work-group produces kFramesPerBlock consecutive frames of one
-// utterance.  The PCM span those frames cover is staged once into LDS with coalesced 16-byte
-// loads (frames overlap 240 of 400 samples, so this removes the 2.5x re-read from HBM); each of
-// the four wavefronts then transforms frames on its own, four complex points per lane, exchanging
-// points between radix-4 stages through a wave-private LDS slab.
+// Work decomposition: one 256-thread work-group produces kFramesPerBlock = 32 consecutive frames of
+// one utterance.  The PCM span those frames cover is staged once into LDS with coalesced 16-byte
+// loads (frames overlap 240 of 400 samples, so this removes the 2.5x re-read from HBM).
+//
+// FFT.  The 512 real samples of a frame are 256 complex points z[n], n = 16 n1 + n2.  Sixteen lanes
+// own one frame (a wavefront works on four frames at once): lane n2 holds the 16 points z[16 n1 + n2]
+// in registers, runs a 16-point FFT over n1 entirely in registers, multiplies by W256^(n2 k1), and the
+// 16 x 16 block is transposed across the 16 lanes through a wave-private LDS tile (one write and one
+// read of 16 float2 per lane - the only exchange of the transform); lane k1 then runs the second
+// 16-point FFT over n2 and holds Z[k1 + 16 k2], k2 = 0..15.  The real-FFT split needs Z[256 - k],
+// which sits in lane (16 - k1) mod 16: one lane permutation per register.
+//
+// Mel filterbank on the matrix pipe.  The power spectrum P[frame][bin] is split into a bf16 high part
+// and a bf16 remainder (relative error 2^-17) and written to LDS; the 80 x 256 weight matrix, split
+// the same way on the host, waits in registers as MFMA operands.  D[filter][frame] = Wh Ph + Wh Pl +
+// Wl Ph with v_mfma_f32_16x16x32_bf16 over 16 frames at a time; only the 12 (filter block, K-step)
+// pairs that hold a non-zero weight are multiplied (the triangles are narrow).  A lane ends up with
+// four consecutive filters of one frame: the log-mel row leaves as 16-byte stores.
 #include "logmel_tables.h"
 #include "oasr_common.h"
 
@@ -17,9 +30,10 @@ constexpr int kWaves = 4;
 constexpr int kSpan = (kFramesPerBlock - 1) * OASR_FRAME_HOP + OASR_FRAME_LEN;  // 5360 samples
 constexpr float kMelFloor = 1.192092955078125e-07f;
 constexpr float kNormEps = 1e-7f;
-constexpr float kPcmScale = 32768.0f;
-constexpr int kMelPitch = kMelWidth + 1;       // odd pitch: lanes reading column i of 64 rows hit distinct banks
-constexpr int kPPitch = 257 + kMelWidth + 3;   // room for a padded triangle starting at the last bin  // Kaldi convention: 16-bit integer range
+constexpr float kPcmScale = 32768.0f;          // Kaldi convention: 16-bit integer range
+constexpr int kTPitch = 17;                    // floats per row of a transpose tile: lanes reading a column hit distinct banks
+constexpr int kPPitchDw = 152;                 // dwords per frame of the split power spectrum: conflict-free fragment reads
+constexpr int kPPlaneDw = 16 * kPPitchDw;
 
 // Orders this wave's LDS writes before its later LDS reads (DS operations of one wave execute in
 // order; this only pins the compiler).
@@ -46,7 +60,7 @@ __device__ __forceinline__ cpx tw512(const LogmelBlob* t, int k) {
     return {s * t->tw_re[k], s * t->tw_im[k]};
 }
 
-// In-place radix-4 decimation-in-frequency butterfly: a[q] <- sum_j a[j] (-i)^(j q)
+// In-place 4-point DFT: a[q] <- sum_j a[j] (-i)^(j q)
 __device__ __forceinline__ void radix4(cpx (&a)[4]) {
     const cpx t0 = cadd(a[0], a[2]), t1 = csub(a[0], a[2]);
     const cpx t2 = cadd(a[1], a[3]), d = csub(a[1], a[3]);
@@ -57,232 +71,359 @@ __device__ __forceinline__ void radix4(cpx (&a)[4]) {
     a[3] = csub(t1, t3);
 }
 
-__global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ pcm,
-                                                     int64_t pcm_stride,
-                                                     const int32_t* __restrict__ n_samples,
-                                                     int64_t frame_cap,
-                                                     const LogmelBlob* __restrict__ tab,
-                                                     float* __restrict__ out,
-                                                     float* __restrict__ stats,
-                                                     int64_t stats_slots) {
-    __shared__ __attribute__((aligned(16))) float span[kSpan + 8];
-    __shared__ __attribute__((aligned(16))) float2 zbuf[kWaves][256];
-    __shared__ float pbuf[kWaves][kPPitch];            // power spectrum; entries >= 257 stay zero
-    __shared__ float melw[81 * kMelPitch];             // padded triangle weights (block copy, odd row pitch)
-    __shared__ float wstat[kWaves][OASR_NMEL][2];
-
-    const int b = blockIdx.y;
-    const int f0 = blockIdx.x * kFramesPerBlock;
-    const int ns = n_samples[b];
-    const int nf = ns < OASR_FRAME_LEN ? 0 : 1 + (ns - OASR_FRAME_LEN) / OASR_FRAME_HOP;
-    const int nf_cap = nf < (int)frame_cap ? nf : (int)frame_cap;
-    float* my_stats = stats + ((int64_t)b * stats_slots + blockIdx.x) * (OASR_NMEL * 2);
-    if (f0 >= nf_cap) {
-        if (threadIdx.x < OASR_NMEL * 2) my_stats[threadIdx.x] = 0.0f;
-        return;
+// 16-point DFT in registers, natural order in and out: X[k] = sum_n a[n] W16^(n k), as two passes of
+// 4-point DFTs (n = 4 na + nb, k = ka + 4 kb) with the W16^(nb ka) twiddles in between.
+__device__ __forceinline__ void fft16(const cpx (&a)[16], cpx (&X)[16]) {
+    constexpr float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, r = 0.70710678118654752f;
+    cpx y[4][4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        cpx v[4] = {a[nb], a[4 + nb], a[8 + nb], a[12 + nb]};
+        radix4(v);
+#pragma unroll
+        for (int ka = 0; ka < 4; ++ka) y[nb][ka] = v[ka];
     }
-    const int nfb = min(kFramesPerBlock, nf_cap - f0);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto mul_w2 = [&](cpx v) { return cpx{(v.re + v.im) * r, (v.im - v.re) * r}; };     // W16^2 = (r, -r)
+    auto mul_w6 = [&](cpx v) { return cpx{(v.im - v.re) * r, -(v.re + v.im) * r}; };    // W16^6 = (-r, -r)
+    y[1][1] = cmul(y[1][1], cpx{c1, -s1});    // W16^1
+    y[1][2] = mul_w2(y[1][2]);
+    y[1][3] = cmul(y[1][3], cpx{s1, -c1});    // W16^3
+    y[2][1] = mul_w2(y[2][1]);
+    y[2][2] = cpx{y[2][2].im, -y[2][2].re};   // W16^4 = -i
+    y[2][3] = mul_w6(y[2][3]);
+    y[3][1] = cmul(y[3][1], cpx{s1, -c1});    // W16^3
+    y[3][2] = mul_w6(y[3][2]);
+    y[3][3] = cmul(y[3][3], cpx{-c1, s1});    // W16^9
+#pragma unroll
+    for (int ka = 0; ka < 4; ++ka) {
+        cpx v[4] = {y[0][ka], y[1][ka], y[2][ka], y[3][ka]};
+        radix4(v);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) X[ka + 4 * kb] = v[kb];
+    }
+}
 
-    // ---- stage the PCM span (16-byte coalesced loads, scalar tail) --------------------------------
+__device__ __forceinline__ uint32_t cvt_pk_bf16_rne(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    bf2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+// Sum over the 16 lanes that share a frame, left in all of them: four rotations within the DPP row
+// (row_ror:8, 4, 2, 1), on the vector ALU - no trip through the LDS crossbar.
+__device__ __forceinline__ float sum16(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+}
+
+// LDS of one work-group (36.6 KB: four work-groups per CU, four waves per SIMD at <= 128 registers):
+//   span   the PCM span of the 16 frames of one iteration, scaled
+//   tabs   window[400] | W256^(c k) for the twiddle between the FFTs [k][c] | W512^(c + 16 k) of the
+//          real-FFT split [k][c] - read where they are used instead of living in registers
+//   pbuf   the split power spectrum of 16 frames (MFMA B operand); between barriers its first 17 KB also
+//          serve as the transpose tiles of the four waves (real and imaginary parts in turn)
+constexpr int kIterFrames = 16;
+constexpr int kIterSpan = (kIterFrames - 1) * OASR_FRAME_HOP + OASR_FRAME_LEN;   // 2800 samples
+constexpr int kTileDw = 16 * kTPitch;                                             // 272 dwords per frame tile
+
+__global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict__ pcm,
+                                                        int64_t pcm_stride,
+                                                        const int32_t* __restrict__ n_samples,
+                                                        int64_t frame_cap,
+                                                        const LogmelBlob* __restrict__ tab,
+                                                        float* __restrict__ out,
+                                                        float* __restrict__ stats,
+                                                        int64_t stats_slots, int blocks_per_utt, int n_items) {
+    __shared__ __attribute__((aligned(16))) float span[kIterSpan + 24];   // + 24: an absent frame's lanes may read (and discard) past the last frame
+    __shared__ __attribute__((aligned(16))) float win[OASR_FRAME_LEN + 16];
+    __shared__ __attribute__((aligned(16))) float2 twm[16 * 16], twp[16 * 16];
+    __shared__ __attribute__((aligned(16))) uint32_t pbuf[2 * kPPlaneDw];
+    static_assert(4 * 4 * kTileDw <= 2 * kPPlaneDw, "transpose tiles must fit the power-spectrum buffer");
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, c = lane & 15;   // frame slot of the wave; n2 in the first FFT, k1 after the transpose
+
+    // ---- tables to LDS (once: the work-group is persistent) -------------------------------------------
+    // the 2^15 scale of the samples (Kaldi's 16-bit range) rides on the window: a power of two, so every
+    // product and difference up to the windowed sample is the scaled one bit for bit
+    for (int i = tid; i < OASR_FRAME_LEN + 16; i += 256) win[i] = i < OASR_FRAME_LEN ? tab->window[i] * kPcmScale : 0.0f;
     {
-        const float* src = pcm + (int64_t)b * pcm_stride + (int64_t)f0 * OASR_FRAME_HOP;
-        const int count = (nfb - 1) * OASR_FRAME_HOP + OASR_FRAME_LEN;
-        const bool aligned = ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
-        if (aligned) {
-            const int n4 = count >> 2;
-            for (int i = tid; i < n4; i += 256) {
-                float4 v = reinterpret_cast<const float4*>(src)[i];
-                v.x *= kPcmScale; v.y *= kPcmScale; v.z *= kPcmScale; v.w *= kPcmScale;
-                reinterpret_cast<float4*>(span)[i] = v;
+        const int k = tid >> 4, cc = tid & 15;
+        const cpx a = tw512(tab, 2 * cc * k), p = tw512(tab, cc + 16 * k);
+        twm[k * 16 + cc] = make_float2(a.re, a.im);
+        twp[k * 16 + cc] = make_float2(p.re, p.im);
+    }
+    // mel weights of this wave's tasks (wave 0: filter blocks 0 and 1; waves 1..3: blocks 2..4)
+    const int task0 = wave == 0 ? 0 : (wave == 1 ? 3 : (wave == 2 ? 5 : 8));
+    const int ntask = wave == 0 ? 3 : (wave == 1 ? 2 : (wave == 2 ? 3 : 4));
+    float* tile = reinterpret_cast<float*>(pbuf) + (4 * wave + q) * kTileDw;
+
+    // A unit is one iteration: 16 frames of one (utterance, block of 32 frames) item.  The work-group is
+    // persistent and walks units u = 0, 1, ...: item blockIdx.x + (u >> 1) * gridDim.x, half u & 1.
+    struct Unit {
+        bool item_ok;     // the item exists
+        int nfb;          // frames of the item (0: the utterance ends before this block)
+        int nfi;          // frames of this unit (0: nothing to do)
+        int b, blk;       // utterance and block index of the item
+        const float* src; // first sample of the unit's span
+    };
+    auto unit_of = [&](int u) {
+        Unit r;
+        const int item = blockIdx.x + (u >> 1) * gridDim.x, it = u & 1;
+        r.item_ok = item < n_items;
+        r.nfb = r.nfi = 0;
+        r.b = r.blk = 0;
+        r.src = pcm;
+        if (r.item_ok) {
+            r.b = item / blocks_per_utt;
+            r.blk = item - r.b * blocks_per_utt;
+            int ns = n_samples[r.b];
+            if (ns > (int)pcm_stride) ns = (int)pcm_stride;       // a row never extends past its pitch
+            const int nf = ns < OASR_FRAME_LEN ? 0 : 1 + (ns - OASR_FRAME_LEN) / OASR_FRAME_HOP;
+            const int nf_cap = nf < (int)frame_cap ? nf : (int)frame_cap;
+            const int f0 = r.blk * kFramesPerBlock;
+            r.nfb = max(0, min(kFramesPerBlock, nf_cap - f0));
+            r.nfi = max(0, min(kIterFrames, r.nfb - kIterFrames * it));
+            r.src = pcm + (int64_t)r.b * pcm_stride + (int64_t)(f0 + kIterFrames * it) * OASR_FRAME_HOP;
+        }
+        return r;
+    };
+    // Asynchronous copy of a unit's PCM span into `span` (global -> LDS directly, no registers), 16 bytes
+    // per lane when the source is 16-byte aligned, else 4.  Written as inline assembly so that the only
+    // waits are the explicit ones: s_waitcnt vmcnt(0) and a barrier before the span is read.
+    typedef __attribute__((address_space(3))) char lds_char;
+    auto stage_span = [&](const Unit& un) {
+        const int count = (un.nfi - 1) * OASR_FRAME_HOP + OASR_FRAME_LEN;      // a multiple of 4
+        if ((reinterpret_cast<uintptr_t>(un.src) & 15) == 0) {
+            for (int base = wave * 256; base < count; base += 1024) {          // wave-uniform loop
+                const uint32_t lds_off = (uint32_t)(uintptr_t)(lds_char*)(span + base);
+                const float* p = un.src + base + 4 * lane;
+                if (base + 4 * lane < count) {
+                    uint32_t saved;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                                 "s_mov_b32 m0, %0"
+                                 : "=&s"(saved) : "v"(p), "s"(lds_off) : "memory");
+                }
             }
-            for (int i = (n4 << 2) + tid; i < count; i += 256) span[i] = src[i] * kPcmScale;
         } else {
-            for (int i = tid; i < count; i += 256) span[i] = src[i] * kPcmScale;
+            for (int base = wave * 64; base < count; base += 256) {
+                const uint32_t lds_off = (uint32_t)(uintptr_t)(lds_char*)(span + base);
+                const float* p = un.src + base + lane;
+                if (base + lane < count) {
+                    uint32_t saved;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\t"
+                                 "s_mov_b32 m0, %0"
+                                 : "=&s"(saved) : "v"(p), "s"(lds_off) : "memory");
+                }
+            }
         }
-    }
+    };
 
-    for (int i = tid; i < 81 * kMelWidth; i += 256) melw[(i / kMelWidth) * kMelPitch + i % kMelWidth] = tab->mel_w[i];
-    for (int i = tid; i < kWaves * kPPitch; i += 256) (&pbuf[0][0])[i] = 0.0f;
-
-    // ---- per-lane constants ------------------------------------------------------------------------
-    // lane holds complex points n = lane + 64 j (j = 0..3), i.e. samples 2n and 2n+1 of the frame
-    float w_even[4], w_odd[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int s = 2 * (lane + 64 * j);
-        w_even[j] = s < OASR_FRAME_LEN ? tab->window[s] : 0.0f;
-        w_odd[j] = s + 1 < OASR_FRAME_LEN ? tab->window[s + 1] : 0.0f;
-    }
-    cpx tw1[3], tw2[3], tw3[3], twp[4];
-#pragma unroll
-    for (int q = 1; q < 4; ++q) {
-        tw1[q - 1] = tw512(tab, 2 * lane * q);          // W256^(n q),  n = lane
-        tw2[q - 1] = tw512(tab, 8 * (lane & 15) * q);   // W64^(n' q),  n' = lane & 15
-        tw3[q - 1] = tw512(tab, 32 * (lane & 3) * q);   // W16^(n'' q), n'' = lane & 3
-    }
-#pragma unroll
-    for (int m = 0; m < 4; ++m) twp[m] = tw512(tab, lane + 64 * m);
-
-    // mel triangles owned by this lane: A = lane, and B = 79 - lane for lane < 16 (the widest
-    // triangles are paired with the narrowest; other lanes point B at the all-zero dummy row 80).
-    // Weights are zero padded to kMelWidth bins, so the sum below is a fixed-length, branch-free loop.
-    const int mjA = lane, mjB = lane < 16 ? 79 - lane : 80;
-    const float* wA = melw + mjA * kMelPitch;
-    const float* wB = melw + mjB * kMelPitch;
-    const int msA = tab->mel_start[mjA], msB = tab->mel_start[mjB];
-
-    float2* z = zbuf[wave];
-    float* p = pbuf[wave];
-    const int qa = lane >> 4, qb = (lane >> 2) & 3, qc = lane & 3;
-
-    // running statistics (shifted by the first value this wave sees)
-    float c0 = 0.f, c1 = 0.f, s1_0 = 0.f, s2_0 = 0.f, s1_1 = 0.f, s2_1 = 0.f;
-    int nw = 0;
-
-    __syncthreads();
-
-    for (int fi = wave; fi < nfb; fi += kWaves) {
-        const float* x = span + fi * OASR_FRAME_HOP;
-        // ---- load, DC removal, pre-emphasis, window -------------------------------------------------
-        float xe[4], xo[4], xp[4];
-        float part = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int s = 2 * (lane + 64 * j);
-            const bool in = s < OASR_FRAME_LEN;  // frame length is even: s+1 is in range too
-            const float2 v = in ? *reinterpret_cast<const float2*>(x + s) : make_float2(0.f, 0.f);
-            xe[j] = v.x;
-            xo[j] = v.y;
-            xp[j] = (in && s > 0) ? x[s - 1] : 0.0f;
-            part += v.x + v.y;
+    f32x4 keep0[2];       // log-mel values of the item's first half: [accumulator]
+    keep0[0] = keep0[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    Unit cur = unit_of(0);
+    if (cur.nfi > 0) stage_span(cur);
+    for (int u = 0; cur.item_ok; ++u) {
+        const Unit nxt = unit_of(u + 1);
+        const int it = u & 1;
+        float* my_stats = stats + ((int64_t)cur.b * stats_slots + cur.blk) * (OASR_NMEL * 2);
+        if (cur.nfi == 0) {                                   // uniform over the work-group
+            if (it == 0 && threadIdx.x < OASR_NMEL * 2) my_stats[threadIdx.x] = 0.0f;   // the utterance ends before this block
+            if (nxt.nfi > 0) {
+                __syncthreads();                              // nobody reads the span any more
+                stage_span(nxt);
+            }
+            cur = nxt;
+            continue;
         }
-        const float mean = wave_sum(part) * (1.0f / OASR_FRAME_LEN);
-        cpx a[4];
+        const int nfb = cur.nfb, nfi = cur.nfi;
+        f32x4 keep1[2];
+        keep1[0] = keep1[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            // this wave's mel weights, re-read every unit (L2-resident) so that they do not occupy
+            // registers during the transforms; the zero the compiler cannot see keeps the loads here
+            bf16x8 wfh[4], wfl[4];
+            {
+                int opaque = 0;
+                asm volatile("" : "+s"(opaque));
+                const uint32_t* fr = &tab->mel_frag[task0 + opaque][0][lane][0];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int s = 2 * (lane + 64 * j);
-            const float fe = xe[j] - mean, fo = xo[j] - mean, fp = xp[j] - mean;
-            // y[i] = f[i] - 0.97 f[i-1];  y[0] = f[0] - 0.97 f[0]
-            const float ye = (s == 0) ? fe - 0.97f * fe : fe - 0.97f * fp;
-            const float yo = fo - 0.97f * fe;
-            a[j].re = ye * w_even[j];   // window is zero beyond the frame
-            a[j].im = yo * w_odd[j];
+                for (int t = 0; t < 4; ++t) {
+                    const int tt = t < ntask ? t : 0;
+                    wfh[t] = *reinterpret_cast<const bf16x8*>(fr + tt * 512);
+                    wfl[t] = *reinterpret_cast<const bf16x8*>(fr + tt * 512 + 256);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the span has landed
+            __syncthreads();   // span staged; every wave has read the previous power spectrum
+            // this lane group's frame within the unit; a group past the unit's last frame repeats that frame
+            // (its results are discarded below), so no lane ever reads samples that were not staged
+            const bool valid = 4 * wave + q < nfi;
+            const int fi = min(4 * wave + q, nfi - 1);
+            const float* x = span + fi * OASR_FRAME_HOP;
+            // ---- load, DC removal, pre-emphasis, window -------------------------------------------------
+            cpx a[16], y1[16];
+            {
+                float2 v[13];
+                float xp[13];
+                float part = 0.f;
+#pragma unroll
+                for (int n1 = 0; n1 < 13; ++n1) {
+                    const int s = 32 * n1 + 2 * c;
+                    v[n1] = *reinterpret_cast<const float2*>(x + s);
+                    xp[n1] = x[s > 0 ? s - 1 : 0];
+                    if (n1 == 12 && s >= OASR_FRAME_LEN) {   // past the frame's 400 samples (lanes c >= 8 of the last step)
+                        v[n1] = make_float2(0.f, 0.f);
+                        xp[n1] = 0.f;
+                    }
+                    part += v[n1].x + v[n1].y;
+                }
+                const float mean = sum16(part) * (1.0f / OASR_FRAME_LEN);
+#pragma unroll
+                for (int n1 = 0; n1 < 13; ++n1) {
+                    const int s = 32 * n1 + 2 * c;
+                    const float2 w = *reinterpret_cast<const float2*>(win + s);   // zero beyond the frame
+                    const float fe = v[n1].x - mean, fo = v[n1].y - mean, fp = xp[n1] - mean;
+                    // y[i] = f[i] - 0.97 f[i-1];  y[0] = f[0] - 0.97 f[0]
+                    const float ye = (n1 == 0 && c == 0) ? fe - 0.97f * fe : fe - 0.97f * fp;
+                    const float yo = fo - 0.97f * fe;
+                    a[n1].re = ye * w.x;
+                    a[n1].im = yo * w.y;
+                }
+#pragma unroll
+                for (int n1 = 13; n1 < 16; ++n1) a[n1] = cpx{0.f, 0.f};
+            }
+            // ---- 256-point complex FFT as 16 x 16 ---------------------------------------------------------
+            fft16(a, y1);
+#pragma unroll
+            for (int k1 = 1; k1 < 16; ++k1) {
+                const float2 w = twm[k1 * 16 + c];
+                y1[k1] = cmul(y1[k1], cpx{w.x, w.y});
+            }
+            // transpose across the 16 lanes of the frame, real parts then imaginary parts
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) tile[k1 * kTPitch + c] = y1[k1].re;
+            OASR_WAVE_SYNC();
+#pragma unroll
+            for (int n2 = 0; n2 < 16; ++n2) a[n2].re = tile[c * kTPitch + n2];
+            OASR_WAVE_SYNC();
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) tile[k1 * kTPitch + c] = y1[k1].im;
+            OASR_WAVE_SYNC();
+#pragma unroll
+            for (int n2 = 0; n2 < 16; ++n2) a[n2].im = tile[c * kTPitch + n2];
+            fft16(a, y1);                                    // y1[k2] = Z[c + 16 k2]
+            // ---- real-FFT split and power: X[k] = E[k] + W512^k O[k], E / O from Z[k] and Z[256 - k] ------
+            float pw[16];
+            {
+                const int partner = (lane & 48) | ((16 - c) & 15);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) a[j] = cpx{__shfl(y1[j].re, partner, 64), __shfl(y1[j].im, partner, 64)};
+#pragma unroll
+                for (int k2 = 0; k2 < 16; ++k2) {
+                    // 256 - (c + 16 k2) = (16 - c) + 16 (15 - k2) for c > 0, 16 (16 - k2) for c = 0
+                    const cpx zm = c == 0 ? a[(16 - k2) & 15] : a[15 - k2];
+                    const cpx zk = y1[k2];
+                    const float2 w = twp[k2 * 16 + c];
+                    const float er = zk.re + zm.re, ei = zk.im - zm.im;        // 2 E
+                    const float orr = zk.im + zm.im, oi = zm.re - zk.re;       // 2 O
+                    const float xr = er + w.x * orr - w.y * oi;
+                    const float xi = ei + w.x * oi + w.y * orr;
+                    pw[k2] = valid ? 0.25f * (xr * xr + xi * xi) : 0.0f;
+                }
+            }
+            __syncthreads();   // every wave is done with its transpose tiles: the buffer becomes the power spectrum
+            // ---- bf16 high part and remainder to LDS: K-step s holds bins 32 s + c (slot 2 c) and
+            //      32 s + 16 + c (slot 2 c + 1) of this lane ----------------------------------------------------
+            {
+                uint32_t* dst = pbuf + (4 * wave + q) * kPPitchDw + c;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const float pa = pw[2 * s], pb = pw[2 * s + 1];
+                    const uint32_t hi = cvt_pk_bf16_rne(pa, pb);
+                    const float ra = pa - __uint_as_float(hi << 16), rb = pb - __uint_as_float(hi & 0xFFFF0000u);
+                    dst[16 * s] = hi;
+                    dst[kPPlaneDw + 16 * s] = cvt_pk_bf16_rne(ra, rb);
+                }
+            }
+            __syncthreads();   // power spectrum written; every wave has read its frames from the span
+            if (nxt.nfi > 0) stage_span(nxt);               // lands while this unit finishes
+            // ---- mel filterbank: D[filter][frame] over this wave's (filter block, K-step) tasks -----------
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            const uint32_t* frag = pbuf + c * kPPitchDw + 4 * q;     // B operand: column = frame c, K slots 8 q .. 8 q + 7
+            auto mm = [&](f32x4 acc, int t, int s) {
+                const bf16x8 ph = *reinterpret_cast<const bf16x8*>(frag + 16 * s);
+                const bf16x8 pl = *reinterpret_cast<const bf16x8*>(frag + kPPlaneDw + 16 * s);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfh[t], ph, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfh[t], pl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfl[t], ph, acc, 0, 0, 0);
+                return acc;
+            };
+            if (wave == 0) {
+                acc0 = mm(acc0, 0, 0);
+                acc1 = mm(acc1, 1, 0);
+                acc1 = mm(acc1, 2, 1);
+            } else if (wave == 1) {
+                acc0 = mm(acc0, 0, 1);
+                acc0 = mm(acc0, 1, 2);
+            } else if (wave == 2) {
+                acc0 = mm(acc0, 0, 2);
+                acc0 = mm(acc0, 1, 3);
+                acc0 = mm(acc0, 2, 4);
+            } else {
+                acc0 = mm(acc0, 0, 4);
+                acc0 = mm(acc0, 1, 5);
+                acc0 = mm(acc0, 2, 6);
+                acc0 = mm(acc0, 3, 7);
+            }
+            // ---- floor, log, store: this lane holds filters 16 blk + 4 q .. + 3 of frame 16 it + c ---------
+            const int col = kIterFrames * it + c;
+            const bool col_ok = col < nfb;
+            const int blk0 = wave == 0 ? 0 : wave + 1;
+            float* dst = out + ((int64_t)cur.b * frame_cap + (cur.blk * kFramesPerBlock + col)) * OASR_NMEL + 4 * q;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) keep1[0][r] = __logf(fmaxf(acc0[r], kMelFloor));
+            if (col_ok) *reinterpret_cast<f32x4*>(dst + 16 * blk0) = keep1[0];
+            if (wave == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) keep1[1][r] = __logf(fmaxf(acc1[r], kMelFloor));
+                if (col_ok) *reinterpret_cast<f32x4*>(dst + 16) = keep1[1];
+            }
         }
-        // ---- 256-point complex FFT, radix-4 DIF, three exchanges through LDS -----------------------
-        radix4(a);
+        if (it == 0 && nfb > kIterFrames) {        // the item's second half follows: keep the values for its statistics
+            keep0[0] = keep1[0];
+            keep0[1] = keep1[1];
+        } else {
+            // ---- per-block (mean, M2) partials over the block's frames, two passes over the kept values --
+            // v0: frames 0..15 of the block, v1: frames 16..31 (absent when the block ends in its first half)
+            const float inv = 1.0f / (float)nfb;
+            const bool ok0 = c < nfb, ok1 = 16 + c < nfb;
 #pragma unroll
-        for (int q = 1; q < 4; ++q) a[q] = cmul(a[q], tw1[q - 1]);
+            for (int a = 0; a < 2; ++a) {
+                if (a == 1 && wave != 0) break;
+                const int blk = a == 1 ? 1 : (wave == 0 ? 0 : wave + 1);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) z[q * 64 + lane] = make_float2(a[q].re, a[q].im);
-        OASR_WAVE_SYNC();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float2 v = z[qa * 64 + (lane & 15) + 16 * j];
-            a[j] = {v.x, v.y};
+                for (int r = 0; r < 4; ++r) {
+                    const float v0 = it == 0 ? keep1[a][r] : keep0[a][r], v1 = keep1[a][r];
+                    const float mean = sum16((ok0 ? v0 : 0.f) + (ok1 ? v1 : 0.f)) * inv;
+                    const float d0 = ok0 ? v0 - mean : 0.f, d1 = ok1 ? v1 - mean : 0.f;
+                    const float m2 = sum16(d0 * d0 + d1 * d1);
+                    if (c == 0) {
+                        const int j = 16 * blk + 4 * q + r;
+                        my_stats[j * 2 + 0] = mean;
+                        my_stats[j * 2 + 1] = m2;
+                    }
+                }
+            }
         }
-        OASR_WAVE_SYNC();
-        radix4(a);
-#pragma unroll
-        for (int q = 1; q < 4; ++q) a[q] = cmul(a[q], tw2[q - 1]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) z[qa * 64 + q * 16 + (lane & 15)] = make_float2(a[q].re, a[q].im);
-        OASR_WAVE_SYNC();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float2 v = z[qa * 64 + qb * 16 + qc + 4 * j];
-            a[j] = {v.x, v.y};
-        }
-        OASR_WAVE_SYNC();
-        radix4(a);
-#pragma unroll
-        for (int q = 1; q < 4; ++q) a[q] = cmul(a[q], tw3[q - 1]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) z[qa * 64 + qb * 16 + q * 4 + qc] = make_float2(a[q].re, a[q].im);
-        OASR_WAVE_SYNC();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float2 v = z[qa * 64 + qb * 16 + qc * 4 + j];
-            a[j] = {v.x, v.y};
-        }
-        OASR_WAVE_SYNC();
-        radix4(a);
-        // lane (qa,qb,qc), register q4 holds Z[64 q4 + 16 qc + 4 qb + qa]: store in natural order
-#pragma unroll
-        for (int q = 0; q < 4; ++q) z[64 * q + 16 * qc + 4 * qb + qa] = make_float2(a[q].re, a[q].im);
-        OASR_WAVE_SYNC();
-        // ---- real-FFT post-processing and power: X[k] = E[k] + W512^k O[k] -------------------------
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int k = lane + 64 * m;
-            const float2 zk = z[k], zm = z[(256 - k) & 255];
-            const float er = 0.5f * (zk.x + zm.x), ei = 0.5f * (zk.y - zm.y);
-            const float orr = 0.5f * (zk.y + zm.y), oi = -0.5f * (zk.x - zm.x);
-            const float xr = er + twp[m].re * orr - twp[m].im * oi;
-            const float xi = ei + twp[m].re * oi + twp[m].im * orr;
-            p[k] = xr * xr + xi * xi;
-        }
-        if (lane == 0) {
-            const float2 z0 = z[0];
-            const float x256 = z0.x - z0.y;
-            p[256] = x256 * x256;
-        }
-        OASR_WAVE_SYNC();
-        // ---- mel triangles, floor, log --------------------------------------------------------------
-        float m0 = 0.f, m1 = 0.f;
-#pragma unroll
-        for (int i = 0; i < kMelWidth; ++i) {
-            m0 = fmaf(wA[i], p[msA + i], m0);
-            m1 = fmaf(wB[i], p[msB + i], m1);
-        }
-        const float l0 = logf(fmaxf(m0, kMelFloor));
-        const float l1 = logf(fmaxf(m1, kMelFloor));
-        OASR_WAVE_SYNC();  // p and z are rewritten by the next frame
-        float* dst = out + ((int64_t)b * frame_cap + (f0 + fi)) * OASR_NMEL;
-        dst[lane] = l0;
-        if (lane < 16) dst[79 - lane] = l1;
-        if (nw == 0) {
-            c0 = l0;
-            c1 = l1;
-        }
-        const float d0 = l0 - c0, d1 = l1 - c1;
-        s1_0 += d0;
-        s2_0 += d0 * d0;
-        s1_1 += d1;
-        s2_1 += d1 * d1;
-        ++nw;
-    }
-
-    // ---- per-block (mean, M2) partials ---------------------------------------------------------------
-    {
-        const float n = (float)nw;
-        const float inv = nw > 0 ? 1.0f / n : 0.0f;
-        wstat[wave][lane][0] = c0 + s1_0 * inv;
-        wstat[wave][lane][1] = fmaxf(s2_0 - s1_0 * s1_0 * inv, 0.0f);
-        if (lane < 16) {
-            wstat[wave][79 - lane][0] = c1 + s1_1 * inv;
-            wstat[wave][79 - lane][1] = fmaxf(s2_1 - s1_1 * s1_1 * inv, 0.0f);
-        }
-    }
-    __syncthreads();
-    if (tid < OASR_NMEL) {
-        float cnt[kWaves], tot = 0.f, mean = 0.f;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-            cnt[w] = w < nfb ? (float)((nfb - w + kWaves - 1) / kWaves) : 0.0f;
-            tot += cnt[w];
-            mean += cnt[w] * wstat[w][tid][0];
-        }
-        mean /= tot;
-        float m2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-            const float dm = wstat[w][tid][0] - mean;
-            m2 += wstat[w][tid][1] + cnt[w] * dm * dm;
-        }
-        my_stats[tid * 2 + 0] = mean;
-        my_stats[tid * 2 + 1] = m2;
-    }
+        cur = nxt;
+    }   // units
 }
 
 // One work-group per utterance: merge the per-block partials (Chan's pairwise update, in double)
@@ -372,10 +513,13 @@ int oasr_logmel_f32(const float* pcm, int64_t pcm_stride, const int32_t* n_sampl
     OASR_REQUIRE(frame_cap > 0 && (frame_cap & 1) == 0, "logmel: frame_cap must be even and positive");
     OASR_REQUIRE(pcm_stride >= OASR_FRAME_LEN, "logmel: pcm_stride shorter than one frame");
     const int64_t slots = oasr_logmel_stats_slots(frame_cap);
-    dim3 grid((unsigned)(slots - 1), (unsigned)batch);
+    const int64_t items = (slots - 1) * (int64_t)batch;
+    OASR_REQUIRE(items < ((int64_t)1 << 31), "logmel: too many frame blocks");
+    // persistent work-groups, four per CU (what LDS and registers allow)
+    dim3 grid((unsigned)(items < 1024 ? items : 1024));
     hipLaunchKernelGGL(logmel_kernel, grid, dim3(256), 0, (hipStream_t)stream, pcm, pcm_stride,
                        n_samples, frame_cap, reinterpret_cast<const LogmelBlob*>(tables), logmel,
-                       stats, slots);
+                       stats, slots, (int)(slots - 1), (int)items);
     OASR_CHECK_LAUNCH("logmel");
     return OASR_OK;
 }

@@ -15,7 +15,18 @@ struct LogmelBlob {
     int32_t mel_width_max;            // widest triangle, in bins (checked against kMelWidth)
     int32_t pad_[2];
     float mel_w[81 * kMelWidth];      // [filter][kMelWidth] weights, zero padded; row 80 is all zeros
+    // The same weights as MFMA operands (v_mfma_f32_16x16x32_bf16, weights = A operand): for each of the
+    // kMelTasks (filter block of 16, K-step of 32 bins) pairs that hold a non-zero weight, the bf16 high
+    // part and the bf16 remainder of the float weight, laid out per lane: lane l holds filter
+    // 16 * block + (l & 15), K slots 8 * (l >> 4) .. + 7, two slots per dword (low half first); slot sigma
+    // of K-step s is FFT bin 32 s + (sigma >> 1) + 16 * (sigma & 1).
+    uint32_t mel_frag[12][2][64][4];
 };
+
+constexpr int kMelTasks = 12;
+// (filter block, K-step) of each task; tasks of one block are consecutive
+constexpr int kMelTaskBlock[kMelTasks] = {0, 1, 1, 2, 2, 3, 3, 3, 4, 4, 4, 4};
+constexpr int kMelTaskStep[kMelTasks] = {0, 0, 1, 1, 2, 2, 3, 4, 4, 5, 6, 7};
 
 int build_logmel_blob(uint32_t* blob);
 
