@@ -81,6 +81,40 @@ def test_logmel_and_features_match_oracle(batch, n_list):
         assert (feats_h[i, nf // 2:] == 0).all()          # padding rows are zero
 
 
+def test_logmel_with_a_row_pitch_that_is_not_16_byte_aligned():
+    """Row pitch 10 002 samples: odd rows start 8 bytes off a 16-byte boundary, so their spans are copied
+    4 bytes per lane instead of 16; 62 frames (one full block of 32, one of 30), the batch's last row
+    ending exactly at the end of the allocation.  Same tolerance as the aligned case."""
+    from oracle import logmel as O
+    H = _lib()
+    batch, stride, n_list = 3, 10002, [10002, 9999, 10002]
+    pcm = synth_pcm(batch, stride, seed=77)
+    for i, n in enumerate(n_list):
+        pcm[i, n:] = 0
+    dev = torch.device("cuda")
+    pcm_d = pcm.to(dev).contiguous()
+    nv = torch.tensor(n_list, dtype=torch.int32, device=dev)
+    cap = 64
+    slots = int(H.lib().oasr_logmel_stats_slots(cap))
+    tables = torch.from_numpy(H.logmel_table_blob().view(np.int32)).to(dev)
+    lm = torch.full((batch, cap, 80), float("nan"), device=dev)
+    stats = torch.zeros((batch, slots, 80, 2), device=dev)
+    H.check(H.lib().oasr_logmel_f32(pcm_d.data_ptr(), stride, nv.data_ptr(), batch, cap, tables.data_ptr(),
+                                    lm.data_ptr(), stats.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    lm_h, st_h = lm.cpu().numpy(), stats.cpu().numpy()
+    for i, n in enumerate(n_list):
+        nf = O.num_frames(n)
+        ref = O.logmel(pcm[i, :n].numpy())
+        np.testing.assert_allclose(lm_h[i, :nf], ref, atol=2e-3, rtol=0)
+        assert np.isnan(lm_h[i, nf:]).all()
+        # per-block partial statistics: (mean, sum of squared deviations) of the block's frames
+        for blk, (lo, hi) in enumerate([(0, 32), (32, nf)]):
+            np.testing.assert_allclose(st_h[i, blk, :, 0], ref[lo:hi].mean(axis=0), atol=2e-3)
+            np.testing.assert_allclose(st_h[i, blk, :, 1], ((ref[lo:hi] - ref[lo:hi].mean(axis=0)) ** 2).sum(axis=0),
+                                       rtol=2e-2, atol=1e-2)
+
+
 # --------------------------------------------------------------------------------------------------
 # LayerNorm
 
