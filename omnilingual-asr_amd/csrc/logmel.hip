@@ -31,8 +31,7 @@ constexpr int kSpan = (kFramesPerBlock - 1) * OASR_FRAME_HOP + OASR_FRAME_LEN;  
 constexpr float kMelFloor = 1.192092955078125e-07f;
 constexpr float kNormEps = 1e-7f;
 constexpr float kPcmScale = 32768.0f;          // Kaldi convention: 16-bit integer range
-constexpr int kTPitch = 17;                    // floats per row of a transpose tile: lanes reading a column hit distinct banks
-constexpr int kPPitchDw = 152;                 // dwords per frame of the split power spectrum: conflict-free fragment reads
+constexpr int kPPitchDw = 128;                 // dwords per frame of the split power spectrum: 8 K-steps x 32 bf16
 constexpr int kPPlaneDw = 16 * kPPitchDw;
 
 // Orders this wave's LDS writes before its later LDS reads (DS operations of one wave execute in
@@ -121,15 +120,21 @@ __device__ __forceinline__ float sum16(float v) {
     return v;
 }
 
-// LDS of one work-group (36.6 KB: four work-groups per CU, four waves per SIMD at <= 128 registers):
+// LDS of one work-group (38.6 KB: four work-groups per CU, four waves per SIMD at <= 128 registers):
 //   span   the PCM span of the 16 frames of one iteration, scaled
 //   tabs   window[400] | W256^(c k) for the twiddle between the FFTs [k][c] | W512^(c + 16 k) of the
 //          real-FFT split [k][c] - read where they are used instead of living in registers
-//   pbuf   the split power spectrum of 16 frames (MFMA B operand); between barriers its first 17 KB also
-//          serve as the transpose tiles of the four waves (real and imaginary parts in turn)
+//   pbuf   the split power spectrum of 16 frames (MFMA B operand): [plane][frame][32 chunks of 16 bytes],
+//          chunk j of frame f stored at chunk j ^ f (conflict-free 16-byte fragment reads without padding);
+//          between barriers the same 16 KB serve as the transpose tiles of the four waves (real and
+//          imaginary parts in turn): tile[k1][c] stored at column c ^ k1, so that both the row-wise
+//          writes and the column-wise reads of 16 lanes touch 16 different banks
+//   obuf   the 16 x 80 log-mel values of a unit, so that they leave as whole 128-byte lines (rows of 320
+//          bytes written 64 bytes at a time would be fetched and written back twice by the memory side)
 constexpr int kIterFrames = 16;
 constexpr int kIterSpan = (kIterFrames - 1) * OASR_FRAME_HOP + OASR_FRAME_LEN;   // 2800 samples
-constexpr int kTileDw = 16 * kTPitch;                                             // 272 dwords per frame tile
+constexpr int kTileDw = 16 * 16;                                                  // dwords per frame tile
+constexpr int kOPitch = OASR_NMEL + 4;                                            // floats per obuf row: 16-byte writes of 16 frames spread over the banks
 
 __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict__ pcm,
                                                         int64_t pcm_stride,
@@ -143,6 +148,7 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
     __shared__ __attribute__((aligned(16))) float win[OASR_FRAME_LEN + 16];
     __shared__ __attribute__((aligned(16))) float2 twm[16 * 16], twp[16 * 16];
     __shared__ __attribute__((aligned(16))) uint32_t pbuf[2 * kPPlaneDw];
+    __shared__ __attribute__((aligned(16))) float obuf[kIterFrames * kOPitch];
     static_assert(4 * 4 * kTileDw <= 2 * kPPlaneDw, "transpose tiles must fit the power-spectrum buffer");
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -162,7 +168,9 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
     // mel weights of this wave's tasks (wave 0: filter blocks 0 and 1; waves 1..3: blocks 2..4)
     const int task0 = wave == 0 ? 0 : (wave == 1 ? 3 : (wave == 2 ? 5 : 8));
     const int ntask = wave == 0 ? 3 : (wave == 1 ? 2 : (wave == 2 ? 3 : 4));
-    float* tile = reinterpret_cast<float*>(pbuf) + (4 * wave + q) * kTileDw;
+    // the frames q = 0, 1 (and 2, 3) of a wave share a tile of 16 rows x 32 dwords, 16 columns each: the two
+    // frames that one LDS pass serves together then sit on different banks
+    float* tile = reinterpret_cast<float*>(pbuf) + (4 * wave + (q & 2)) * kTileDw + 16 * (q & 1);
 
     // A unit is one iteration: 16 frames of one (utterance, block of 32 frames) item.  The work-group is
     // persistent and walks units u = 0, 1, ...: item blockIdx.x + (u >> 1) * gridDim.x, half u & 1.
@@ -225,8 +233,17 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
         }
     };
 
-    f32x4 keep0[2];       // log-mel values of the item's first half: [accumulator]
-    keep0[0] = keep0[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float* pend_dst = nullptr;   // log-mel rows waiting in obuf: where they go and how many float4 (uniform)
+    int pend_vec = 0;
+    auto flush = [&]() {         // call after a barrier that follows the writes to obuf
+        if (pend_dst) {
+            for (int i = tid; i < pend_vec; i += 256) {
+                const int row = i / (OASR_NMEL / 4), col = i - row * (OASR_NMEL / 4);
+                reinterpret_cast<float4*>(pend_dst)[i] = *reinterpret_cast<const float4*>(obuf + row * kOPitch + 4 * col);
+            }
+            pend_dst = nullptr;
+        }
+    };
     Unit cur = unit_of(0);
     if (cur.nfi > 0) stage_span(cur);
     for (int u = 0; cur.item_ok; ++u) {
@@ -235,33 +252,19 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
         float* my_stats = stats + ((int64_t)cur.b * stats_slots + cur.blk) * (OASR_NMEL * 2);
         if (cur.nfi == 0) {                                   // uniform over the work-group
             if (it == 0 && threadIdx.x < OASR_NMEL * 2) my_stats[threadIdx.x] = 0.0f;   // the utterance ends before this block
-            if (nxt.nfi > 0) {
-                __syncthreads();                              // nobody reads the span any more
-                stage_span(nxt);
-            }
+            __syncthreads();                                  // obuf is complete; nobody reads the span any more
+            flush();
+            if (nxt.nfi > 0) stage_span(nxt);
             cur = nxt;
             continue;
         }
         const int nfb = cur.nfb, nfi = cur.nfi;
-        f32x4 keep1[2];
-        keep1[0] = keep1[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 keep0[2], keep1[2];   // log-mel values of this lane, first and second half of the item: [accumulator]
+        keep0[0] = keep0[1] = keep1[0] = keep1[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
         {
-            // this wave's mel weights, re-read every unit (L2-resident) so that they do not occupy
-            // registers during the transforms; the zero the compiler cannot see keeps the loads here
-            bf16x8 wfh[4], wfl[4];
-            {
-                int opaque = 0;
-                asm volatile("" : "+s"(opaque));
-                const uint32_t* fr = &tab->mel_frag[task0 + opaque][0][lane][0];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int tt = t < ntask ? t : 0;
-                    wfh[t] = *reinterpret_cast<const bf16x8*>(fr + tt * 512);
-                    wfl[t] = *reinterpret_cast<const bf16x8*>(fr + tt * 512 + 256);
-                }
-            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the span has landed
-            __syncthreads();   // span staged; every wave has read the previous power spectrum
+            __syncthreads();   // span staged; every wave has read the previous power spectrum and written its part of obuf
+            flush();           // the previous unit's log-mel rows, as whole lines
             // this lane group's frame within the unit; a group past the unit's last frame repeats that frame
             // (its results are discarded below), so no lane ever reads samples that were not staged
             const bool valid = 4 * wave + q < nfi;
@@ -308,16 +311,16 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
             }
             // transpose across the 16 lanes of the frame, real parts then imaginary parts
 #pragma unroll
-            for (int k1 = 0; k1 < 16; ++k1) tile[k1 * kTPitch + c] = y1[k1].re;
+            for (int k1 = 0; k1 < 16; ++k1) tile[k1 * 32 + (c ^ k1)] = y1[k1].re;
             OASR_WAVE_SYNC();
 #pragma unroll
-            for (int n2 = 0; n2 < 16; ++n2) a[n2].re = tile[c * kTPitch + n2];
+            for (int n2 = 0; n2 < 16; ++n2) a[n2].re = tile[c * 32 + (n2 ^ c)];
             OASR_WAVE_SYNC();
 #pragma unroll
-            for (int k1 = 0; k1 < 16; ++k1) tile[k1 * kTPitch + c] = y1[k1].im;
+            for (int k1 = 0; k1 < 16; ++k1) tile[k1 * 32 + (c ^ k1)] = y1[k1].im;
             OASR_WAVE_SYNC();
 #pragma unroll
-            for (int n2 = 0; n2 < 16; ++n2) a[n2].im = tile[c * kTPitch + n2];
+            for (int n2 = 0; n2 < 16; ++n2) a[n2].im = tile[c * 32 + (n2 ^ c)];
             fft16(a, y1);                                    // y1[k2] = Z[c + 16 k2]
             // ---- real-FFT split and power: X[k] = E[k] + W512^k O[k], E / O from Z[k] and Z[256 - k] ------
             float pw[16];
@@ -338,28 +341,46 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
                     pw[k2] = valid ? 0.25f * (xr * xr + xi * xi) : 0.0f;
                 }
             }
+            // this wave's mel weights, re-read every unit (L2-resident) and only now, so that they do not
+            // occupy registers during the transforms; the zero the compiler cannot see keeps the loads here
+            bf16x8 wfh[4], wfl[4];
+            {
+                int opaque = 0;
+                asm volatile("" : "+s"(opaque));
+                const uint32_t* fr = &tab->mel_frag[task0 + opaque][0][lane][0];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int tt = t < ntask ? t : 0;
+                    wfh[t] = *reinterpret_cast<const bf16x8*>(fr + tt * 512);
+                    wfl[t] = *reinterpret_cast<const bf16x8*>(fr + tt * 512 + 256);
+                }
+            }
             __syncthreads();   // every wave is done with its transpose tiles: the buffer becomes the power spectrum
             // ---- bf16 high part and remainder to LDS: K-step s holds bins 32 s + c (slot 2 c) and
             //      32 s + 16 + c (slot 2 c + 1) of this lane ----------------------------------------------------
             {
-                uint32_t* dst = pbuf + (4 * wave + q) * kPPitchDw + c;
+                // frame f = 4 wave + q; dword 16 s + c of its row lives in chunk (4 s + (c >> 2)) ^ f
+                //   = 4 (s ^ wave) + ((c >> 2) ^ q): the K-step part of the swizzle is wave-uniform
+                uint32_t* dst = pbuf + (4 * wave + q) * kPPitchDw + 4 * ((c >> 2) ^ q) + (c & 3);
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
                     const float pa = pw[2 * s], pb = pw[2 * s + 1];
                     const uint32_t hi = cvt_pk_bf16_rne(pa, pb);
                     const float ra = pa - __uint_as_float(hi << 16), rb = pb - __uint_as_float(hi & 0xFFFF0000u);
-                    dst[16 * s] = hi;
-                    dst[kPPlaneDw + 16 * s] = cvt_pk_bf16_rne(ra, rb);
+                    dst[16 * (s ^ wave)] = hi;
+                    dst[kPPlaneDw + 16 * (s ^ wave)] = cvt_pk_bf16_rne(ra, rb);
                 }
             }
             __syncthreads();   // power spectrum written; every wave has read its frames from the span
             if (nxt.nfi > 0) stage_span(nxt);               // lands while this unit finishes
             // ---- mel filterbank: D[filter][frame] over this wave's (filter block, K-step) tasks -----------
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            const uint32_t* frag = pbuf + c * kPPitchDw + 4 * q;     // B operand: column = frame c, K slots 8 q .. 8 q + 7
+            // B operand: column = frame c, K slots 8 q .. 8 q + 7 = chunk (4 s + q) ^ c = 4 (s ^ (c >> 2)) + (q ^ (c & 3))
+            const uint32_t* frag = pbuf + c * kPPitchDw + 4 * (q ^ (c & 3));
+            const int fh = c >> 2;
             auto mm = [&](f32x4 acc, int t, int s) {
-                const bf16x8 ph = *reinterpret_cast<const bf16x8*>(frag + 16 * s);
-                const bf16x8 pl = *reinterpret_cast<const bf16x8*>(frag + kPPlaneDw + 16 * s);
+                const bf16x8 ph = *reinterpret_cast<const bf16x8*>(frag + 16 * (s ^ fh));
+                const bf16x8 pl = *reinterpret_cast<const bf16x8*>(frag + kPPlaneDw + 16 * (s ^ fh));
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfh[t], ph, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfh[t], pl, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfl[t], ph, acc, 0, 0, 0);
@@ -383,23 +404,27 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
                 acc0 = mm(acc0, 3, 7);
             }
             // ---- floor, log, store: this lane holds filters 16 blk + 4 q .. + 3 of frame 16 it + c ---------
-            const int col = kIterFrames * it + c;
-            const bool col_ok = col < nfb;
             const int blk0 = wave == 0 ? 0 : wave + 1;
-            float* dst = out + ((int64_t)cur.b * frame_cap + (cur.blk * kFramesPerBlock + col)) * OASR_NMEL + 4 * q;
+            float* orow = obuf + c * kOPitch + 4 * q;
+            // the item's first half still sits in obuf where this lane wrote it (already copied out): the
+            // statistics below need it, and it costs no registers in between
+            if (it == 1) {
+                keep0[0] = *reinterpret_cast<const f32x4*>(orow + 16 * blk0);
+                if (wave == 0) keep0[1] = *reinterpret_cast<const f32x4*>(orow + 16);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) keep1[0][r] = __logf(fmaxf(acc0[r], kMelFloor));
-            if (col_ok) *reinterpret_cast<f32x4*>(dst + 16 * blk0) = keep1[0];
+            *reinterpret_cast<f32x4*>(orow + 16 * blk0) = keep1[0];
             if (wave == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) keep1[1][r] = __logf(fmaxf(acc1[r], kMelFloor));
-                if (col_ok) *reinterpret_cast<f32x4*>(dst + 16) = keep1[1];
+                *reinterpret_cast<f32x4*>(orow + 16) = keep1[1];
             }
+            // the unit's rows are contiguous in the output: they leave together after the next barrier
+            pend_dst = out + ((int64_t)cur.b * frame_cap + (cur.blk * kFramesPerBlock + kIterFrames * it)) * OASR_NMEL;
+            pend_vec = nfi * (OASR_NMEL / 4);
         }
-        if (it == 0 && nfb > kIterFrames) {        // the item's second half follows: keep the values for its statistics
-            keep0[0] = keep1[0];
-            keep0[1] = keep1[1];
-        } else {
+        if (!(it == 0 && nfb > kIterFrames)) {     // the item is complete (its second half, or a first half that ends it)
             // ---- per-block (mean, M2) partials over the block's frames, two passes over the kept values --
             // v0: frames 0..15 of the block, v1: frames 16..31 (absent when the block ends in its first half)
             const float inv = 1.0f / (float)nfb;
@@ -424,6 +449,8 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
         }
         cur = nxt;
     }   // units
+    __syncthreads();
+    flush();
 }
 
 // One work-group per utterance: merge the per-block partials (Chan's pairwise update, in double)
