@@ -156,9 +156,10 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
     const int q = lane >> 4, c = lane & 15;   // frame slot of the wave; n2 in the first FFT, k1 after the transpose
 
     // ---- tables to LDS (once: the work-group is persistent) -------------------------------------------
-    // the 2^15 scale of the samples (Kaldi's 16-bit range) rides on the window: a power of two, so every
-    // product and difference up to the windowed sample is the scaled one bit for bit
-    for (int i = tid; i < OASR_FRAME_LEN + 16; i += 256) win[i] = i < OASR_FRAME_LEN ? tab->window[i] * kPcmScale : 0.0f;
+    // the 2^15 scale of the samples (Kaldi's 16-bit range) rides on the window, and so does the 1/2 of the
+    // real-FFT split (E = (Z[k] + conj Z[256-k]) / 2): powers of two, so every product, sum and difference
+    // downstream is the scaled one bit for bit
+    for (int i = tid; i < OASR_FRAME_LEN + 16; i += 256) win[i] = i < OASR_FRAME_LEN ? tab->window[i] * (0.5f * kPcmScale) : 0.0f;
     {
         const int k = tid >> 4, cc = tid & 15;
         const cpx a = tw512(tab, 2 * cc * k), p = tw512(tab, cc + 16 * k);
@@ -267,7 +268,6 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
             flush();           // the previous unit's log-mel rows, as whole lines
             // this lane group's frame within the unit; a group past the unit's last frame repeats that frame
             // (its results are discarded below), so no lane ever reads samples that were not staged
-            const bool valid = 4 * wave + q < nfi;
             const int fi = min(4 * wave + q, nfi - 1);
             const float* x = span + fi * OASR_FRAME_HOP;
             // ---- load, DC removal, pre-emphasis, window -------------------------------------------------
@@ -334,11 +334,11 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
                     const cpx zm = c == 0 ? a[(16 - k2) & 15] : a[15 - k2];
                     const cpx zk = y1[k2];
                     const float2 w = twp[k2 * 16 + c];
-                    const float er = zk.re + zm.re, ei = zk.im - zm.im;        // 2 E
-                    const float orr = zk.im + zm.im, oi = zm.re - zk.re;       // 2 O
+                    const float er = zk.re + zm.re, ei = zk.im - zm.im;        // E (the 1/2 is in the window)
+                    const float orr = zk.im + zm.im, oi = zm.re - zk.re;       // O
                     const float xr = er + w.x * orr - w.y * oi;
                     const float xi = ei + w.x * oi + w.y * orr;
-                    pw[k2] = valid ? 0.25f * (xr * xr + xi * xi) : 0.0f;
+                    pw[k2] = xr * xr + xi * xi;
                 }
             }
             // this wave's mel weights, re-read every unit (L2-resident) and only now, so that they do not
