@@ -105,7 +105,7 @@ __global__ __launch_bounds__(HD * 4, HD == 64 ? 3 : 1) void attention_relkey_ker
     }
     const int qb = item % q_blocks;
     const int head = (item / q_blocks) % n_heads, b = item / (q_blocks * n_heads);
-    const int len = lengths[b];
+    const int len = min(lengths[b], t_pad);   // a length past the row pitch would walk into the next utterance
     const int q_blk0 = qb * kQBlock;
     if (q_blk0 >= len) return;  // whole block is padding (uniform)
     const int ld = 3 * d_model;

@@ -216,6 +216,31 @@ def test_bench_long_audio_mode_runs(tmp_path):
     assert line["unit"] == "x real time" and line["steps"] == 2
 
 
+def test_two_ranks_share_the_gpu_through_the_long_audio_mode():
+    """The N > 1 path on the device: two ranks (gloo, both on GPU 0, as `--share-gpu` allows for rehearsal)
+    run `bench.py --hours`: each plans the same chunks, takes its contiguous shard, runs the chunk loop on
+    the device, and the records of both (tokens included) cross in the one all-gather; rank 0 checks that
+    every chunk is present, in order, with the planned bounds."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(root / "bench.py"), "--gpus", "2", "--hours", "0.06", "--model", "GTINY",
+           "--batch", "3", "--backend", "gloo", "--share-gpu"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=str(root))
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["chunks"] == 8 and line["config"]["chunks_per_rank"] == 4
+    assert line["steps"] == 2 and line["value"] > 0            # 4 chunks per rank in batches of 3 + 1
+
+
 def test_four_threads_share_one_pipeline(tmp_path):
     """The reference's server runs up to four `transcribe()` calls at once on one shared instance
     (ref:workflows/wav2elan_web/app.py:383-399): results must equal the one-at-a-time results."""
