@@ -82,8 +82,8 @@ int64_t oasr_num_stacked(int64_t n_samples);
  * mel_weights[257*80] row-major [bin][filter]. */
 int oasr_logmel_tables(float* window, float* mel_weights);
 
-/* The same tables (plus FFT twiddles and the sparse form of the mel triangles) packed as the
- * device blob the kernel reads.  The library keeps no device-side state: the caller copies the
+/* The same tables (plus FFT twiddles and the mel triangles as bf16 high part + remainder in the
+ * operand layout of the matrix instructions that apply them) packed as the device blob the kernel reads.  The library keeps no device-side state: the caller copies the
  * blob to each device once and passes its device address to oasr_logmel_f32. */
 int64_t oasr_logmel_table_words(void);
 int oasr_logmel_table_blob(uint32_t* blob, int64_t capacity_words);
