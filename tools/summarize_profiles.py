@@ -51,7 +51,8 @@ for mode, cmd in (("graph", "python3 bench.py --steps 10 --warmup 3 --no-cpu-bas
         log = out / ("%s_stats_%s.log" % (tag, mode))
         last = [l for l in log.read_text().splitlines() if l.startswith("{")]
         md += ["## `rocprofv3 --kernel-trace --stats -- %s`" % cmd, "",
-               "13 forwards (3 warm-up + 10 timed) plus the event-timed launches (21 each) of the kernels bench.py reports",
+               "Warm-up and timed forwards of the resident batch, the same batch through the upload + CTC path, and the",
+               "event-timed launches (21 each) of the kernels bench.py reports",
                "roofline lines for: the three GEMM shapes of a block with the kernels that feed them, attention, log-mel.",
                "`gemm_bf16_kernel<E, L>`: E = epilogue (0 bias, 1 bias+Swish, 2 GLU, 3 float32 residual, 4 float32 bias),",
                "L = true for K >= 2048 (the FFN down-projection), false for the K = 1024 projections.", "", table, ""]
