@@ -26,8 +26,6 @@
 namespace oasr {
 
 constexpr int kFramesPerBlock = 32;
-constexpr int kWaves = 4;
-constexpr int kSpan = (kFramesPerBlock - 1) * OASR_FRAME_HOP + OASR_FRAME_LEN;  // 5360 samples
 constexpr float kMelFloor = 1.192092955078125e-07f;
 constexpr float kNormEps = 1e-7f;
 constexpr float kPcmScale = 32768.0f;          // Kaldi convention: 16-bit integer range
