@@ -98,7 +98,9 @@ int oasr_logmel_table_blob(uint32_t* blob, int64_t capacity_words);
  *            frames it produced, consumed by oasr_feature_norm_stack;
  *            stats_slots = oasr_logmel_stats_slots(frame_cap); the last slot is reserved for the
  *            merged (mean, 1/std) that oasr_feature_norm_stack writes
- * Requires frame_cap even and pcm_stride >= the longest row. */
+ * Requires frame_cap even and pcm_stride >= the longest row: n_samples[b] <= pcm_stride for every row
+ * (oasr_logmel_f32 clamps a larger value to the pitch, so nothing outside the row is read, but the
+ * statistics of oasr_feature_norm_stack are only defined when the caller keeps this bound). */
 int64_t oasr_logmel_stats_slots(int64_t frame_cap);
 int oasr_logmel_f32(const float* pcm, int64_t pcm_stride, const int32_t* n_samples, int32_t batch,
                     int64_t frame_cap, const uint32_t* tables, float* logmel, float* stats,
