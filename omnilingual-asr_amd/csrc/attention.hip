@@ -188,6 +188,8 @@ __global__ __launch_bounds__(HD * 4, HD == 64 ? 3 : 1) void attention_relkey_ker
     // of each tile), which would make the prefetch of tile kt+1 wait in the middle of tile kt.  The
     // ordering that matters is explicit here: vmcnt(0) and a barrier at the end of every tile.
     typedef __attribute__((address_space(3))) char lds_char;
+    typedef __attribute__((address_space(3))) _Float16 lds_half;
+    const int qe_lds = (int)(uint32_t)(uintptr_t)(lds_char*)(char*)qe;   // LDS byte address of this wave's table
     auto dma16 = [&](const uint16_t* src, char* dst) {   // dst: wave-uniform LDS address of a 1 KiB piece
         const uint32_t lds_off = (uint32_t)(uintptr_t)(lds_char*)dst;
         uint32_t saved;                       // M0 is left as it was found: the compiler reserves it
@@ -195,25 +197,30 @@ __global__ __launch_bounds__(HD * 4, HD == 64 ? 3 : 1) void attention_relkey_ker
                      "s_mov_b32 m0, %0"
                      : "=&s"(saved) : "v"(src), "s"(lds_off) : "memory");
     };
-    auto stage_tile = [&](int buf, int kt) {   // tiles are staged in order: the pointers advance by one tile
-        char* kdst = sm.k[buf] + wave * 1024;
-        char* vdst = sm.v[buf] + wave * 1024;
-        if ((kt + 1) * kKTile <= t_pad) {
-            dma16(kp0, kdst);
-            dma16(kp0 + half_step, kdst + kWaves * 1024);
-            dma16(vp0, vdst);
-            dma16(vp0 + half_step, vdst + kWaves * 1024);
-        } else {
+    // Source pointers of this wave's four pieces of tile kt (K rows, K rows + 32, V rows, V rows + 32).
+    // Tiles are staged in order: the base pointers advance by one tile per call.  A tile that reaches
+    // past row t_pad - 1 (only the last one, or the tile after the last that the final iteration
+    // requests and nobody reads) has its rows clamped.
+    struct Pieces { const uint16_t* src[4]; };
+    auto next_pieces = [&](int kt) {
+        Pieces pc;
+        int64_t back0 = 0, back1 = 0;
+        if ((kt + 1) * kKTile > t_pad) {
             const int k0 = kt * kKTile;
-            const int64_t back0 = (int64_t)(k0 + prow - min(k0 + prow, last_row)) * ld;
-            const int64_t back1 = (int64_t)(k0 + 32 + prow - min(k0 + 32 + prow, last_row)) * ld;
-            dma16(kp0 - back0, kdst);
-            dma16(kp0 + half_step - back1, kdst + kWaves * 1024);
-            dma16(vp0 - back0, vdst);
-            dma16(vp0 + half_step - back1, vdst + kWaves * 1024);
+            back0 = (int64_t)(k0 + prow - min(k0 + prow, last_row)) * ld;
+            back1 = (int64_t)(k0 + 32 + prow - min(k0 + 32 + prow, last_row)) * ld;
         }
+        pc.src[0] = kp0 - back0;
+        pc.src[1] = kp0 + half_step - back1;
+        pc.src[2] = vp0 - back0;
+        pc.src[3] = vp0 + half_step - back1;
         kp0 += tile_step;
         vp0 += tile_step;
+        return pc;
+    };
+    auto stage_piece = [&](int buf, const Pieces& pc, int i) {
+        char* dst = (i < 2 ? sm.k[buf] : sm.v[buf]) + wave * 1024 + (i & 1) * (kWaves * 1024);
+        dma16(pc.src[i], dst);
     };
 
     // K fragment addresses: lane (r, hh) reads key r (+32), logical chunk 2 s + hh
@@ -234,7 +241,11 @@ __global__ __launch_bounds__(HD * 4, HD == 64 ? 3 : 1) void attention_relkey_ker
         v_frag[db] = key * kRowB + ((((cbyte >> 4) ^ vswz<HD>(key)) << 4) | (cbyte & 15));
     }
 
-    stage_tile(0, 0);
+    {
+        const Pieces pc = next_pieces(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stage_piece(0, pc, i);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -247,24 +258,17 @@ __global__ __launch_bounds__(HD * 4, HD == 64 ? 3 : 1) void attention_relkey_ker
     auto process_tile = [&](auto kind_c, int kt) {
         constexpr int KIND = decltype(kind_c)::value;
         const int buf = kt & 1;
-        // request tile kt+1 into the other buffer (free since the barrier that ended tile kt-1)
-        if (kt + 1 < n_tiles) stage_tile(buf ^ 1, kt + 1);
+        // Tile kt+1 goes into the other buffer (free since the barrier that ended tile kt-1).  Its four
+        // copies are issued between the MFMAs of S^T, one per pair: a copy holds the wave's issue for
+        // ~100 cycles, which the matrix pipe spends on the pair before it.  The last iteration requests
+        // one tile more than exists (rows clamped, nobody reads it) so that the loop has no branch here.
+        const Pieces pc = next_pieces(kt + 1);
         if (wave_active) {
             const int k0 = kt * kKTile;
             const char* kbuf = sm.k[buf];
             const char* vbuf = sm.v[buf];
-            // ---- S^T = K . Q^T for the two 32-key halves (relative to m_run in the FAR case) ---------------
-            f32x16 s0, s1;
-            if (KIND == FAR) {
-                s0 = offv;
-                s1 = offv;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    s0[e] = 0.f;
-                    s1[e] = 0.f;
-                }
-            }
+            // ---- S^T = K . Q^T for the two 32-key halves; the accumulators start from offv ------------------
+            f32x16 s0 = offv, s1 = offv;   // FAR: bias - m_run; otherwise -m_run
             // K fragments of four k-steps are requested together, so the MFMAs wait for the LDS once per
             // group instead of once per pair
 #pragma unroll
@@ -279,20 +283,31 @@ __global__ __launch_bounds__(HD * 4, HD == 64 ? 3 : 1) void attention_relkey_ker
                 for (int j = 0; j < 4; ++j) {
                     s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[j], qf[s4 + j], s0, 0, 0, 0);
                     s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[j], qf[s4 + j], s1, 0, 0, 0);
+                    if (s4 == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        stage_piece(buf ^ 1, pc, j);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
-                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // the 8 LDS reads first ...
-                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // ... then the 8 MFMAs
+                if (s4 != 0) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);   // the 8 LDS reads first ...
+                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // ... then the 8 MFMAs
+                }
             }
             if (KIND != FAR) {
-                // c = clamp(key - q, -L, R) + L = med3(dbase + krow, 0, L + R)
-                const int dbase = k0 - (qw0 + r) + left_max + 4 * hh;
+                // table entry (c, r) lies at LDS byte qe_lds + 64 c + 2 r with c = clamp(key - q, -L, R) + L:
+                // one add and one three-operand median give the address (the accumulators already hold
+                // score - m_run, so the entry is only converted and added)
+                const int cb64 = qe_lds + (k0 - (qw0 + r) + left_max + 4 * hh) * 64 + 2 * r;
+                const int lo = qe_lds + 2 * r, hi = lo + (n_dist - 1) * 64;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int krow = (e & 3) + 8 * (e >> 2);
-                    const int c0 = min(max(dbase + krow, 0), n_dist - 1);
-                    const int c1 = min(max(dbase + krow + 32, 0), n_dist - 1);
-                    const float t0 = s0[e] + ((float)qe[c0 * 32 + r] - m_run);
-                    const float t1 = s1[e] + ((float)qe[c1 * 32 + r] - m_run);
+                    int a0 = cb64 + krow * 64, a1 = cb64 + (krow + 32) * 64;
+                    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(a0) : "v"(a0), "v"(lo), "v"(hi));
+                    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(a1) : "v"(a1), "v"(lo), "v"(hi));
+                    const float t0 = s0[e] + (float)*(const lds_half*)(uintptr_t)(uint32_t)a0;
+                    const float t1 = s1[e] + (float)*(const lds_half*)(uintptr_t)(uint32_t)a1;
                     if (KIND == NEAR_MASKED) {
                         const int key = k0 + krow + 4 * hh;
                         s0[e] = key < len ? t0 : -INFINITY;
@@ -370,10 +385,14 @@ __global__ __launch_bounds__(HD * 4, HD == 64 ? 3 : 1) void attention_relkey_ker
                 }
             }
         }
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) stage_piece(buf ^ 1, pc, i);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt+1 have landed
         __syncthreads();  // tile kt+1 is staged; everyone is done reading buffer kt & 1
     };
-    // start value of the S^T accumulators in FAR tiles
+    // start value of the S^T accumulators: (bias - m_run) in FAR tiles, -m_run in the others
     auto set_far_bias = [&](float bias) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) offv[e] = bias - m_run;
@@ -392,9 +411,11 @@ __global__ __launch_bounds__(HD * 4, HD == 64 ? 3 : 1) void attention_relkey_ker
     int kt = 0;
     set_far_bias(bias_left);
     for (; kt < n_left; ++kt) process_tile(std::integral_constant<int, FAR>{}, kt);
+    set_far_bias(0.f);
     for (; kt < first_r; ++kt) process_tile(std::integral_constant<int, NEAR>{}, kt);
     set_far_bias(bias_right);
     for (; kt < n_full; ++kt) process_tile(std::integral_constant<int, FAR>{}, kt);
+    set_far_bias(0.f);
     for (; kt < n_tiles; ++kt) process_tile(std::integral_constant<int, NEAR_MASKED>{}, kt);
 
     if (!wave_active) return;
