@@ -425,18 +425,32 @@ __global__ __launch_bounds__(HD * 4, HD == 64 ? 3 : 1) void attention_relkey_ker
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lsum), __float_as_uint(lsum), false, false);
         inv = 1.0f / (__uint_as_float(sw[0]) + __uint_as_float(sw[1]));
     }
-    const int q = qw0 + r;
-    if (q < t_pad) {
-        uint16_t* op = ctx + ((int64_t)b * t_pad + q) * d_model + head * kHead + 4 * hh;
+    // The wave's 32 x HD output tile crosses LDS once (the K/V buffers are free: every wave is past the
+    // last barrier and no copy is in flight), so that it leaves as whole rows: a lane holds 8-byte pieces
+    // of one row, and stored from there each instruction would touch 64 different lines.  Layout of the
+    // wave's strip: row q at q * kRowB, 16-byte chunk c at position c ^ (q % kCpr).
+    char* strip = sm.k[0] + wave * (32 * kRowB);   // k and v are contiguous: 4 x 4 KiB or 8 x 8 KiB
 #pragma unroll
-        for (int db = 0; db < kOut; ++db) {
+    for (int db = 0; db < kOut; ++db) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const uint2 pk = make_uint2(cvt_pk_bf16(o[db][4 * g] * inv, o[db][4 * g + 1] * inv),
-                                            cvt_pk_bf16(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv));
-                *reinterpret_cast<uint2*>(op + 32 * db + 8 * g) = pk;
-            }
+        for (int g = 0; g < 4; ++g) {
+            const uint2 pk = make_uint2(cvt_pk_bf16(o[db][4 * g] * inv, o[db][4 * g + 1] * inv),
+                                        cvt_pk_bf16(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv));
+            const int chunk = 4 * db + g;   // channels 32 db + 8 g + 4 hh .. + 3: half hh of chunk 4 db + g
+            *reinterpret_cast<uint2*>(strip + r * kRowB + ((chunk ^ (r & (kCpr - 1))) << 4) + 8 * hh) = pk;
         }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    constexpr int kRowsPerStore = 64 / kCpr;   // 8 or 4 whole rows per store instruction
+    const int srow = lane / kCpr, schunk = lane % kCpr;
+    uint16_t* op = ctx + ((int64_t)b * t_pad + qw0) * d_model + head * kHead + 8 * schunk;
+#pragma unroll
+    for (int i = 0; i < 32 / kRowsPerStore; ++i) {
+        const int q = i * kRowsPerStore + srow;
+        const uint4 v = *reinterpret_cast<const uint4*>(strip + q * kRowB + ((schunk ^ (q & (kCpr - 1))) << 4));
+        if (qw0 + q < t_pad) *reinterpret_cast<uint4*>(op + (int64_t)q * d_model) = v;
     }
 }
 
