@@ -47,12 +47,17 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
 // max would read accumulators the matrix pipe has not written yet.)
 __device__ __forceinline__ float vmax(float a, float b) { return __builtin_fmaxf(a, b); }
 __device__ __forceinline__ float vmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
-// max over the 32 scores a lane holds
+// max over the 32 scores a lane holds: four chains of four dependent instructions, not one of sixteen
 __device__ __forceinline__ float max32(const f32x16& a, const f32x16& b) {
-    float m = vmax(a[0], b[0]);
+    float m[4];
 #pragma unroll
-    for (int e = 1; e < 16; ++e) m = vmax3(m, a[e], b[e]);
-    return m;
+    for (int c = 0; c < 4; ++c) m[c] = vmax(a[c], b[c]);
+#pragma unroll
+    for (int e = 4; e < 16; e += 4) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) m[c] = vmax3(m[c], a[e + c], b[e + c]);
+    }
+    return vmax(vmax3(m[0], m[1], m[2]), m[3]);
 }
 
 // LDS images, double buffered (one barrier per key tile):
@@ -319,14 +324,14 @@ __global__ __launch_bounds__(HD * 4, HD == 64 ? 3 : 1) void attention_relkey_ker
                 }
             }
             // ---- raise the running max if needed (always on the first tile) ---------------------------------
+            // A lane sees the 32 keys of its half; the other half of its query's keys lives in lane ^ 32.
+            // The common case needs no exchange: no lane of the wave is past the threshold.
             float tmax = max32(s0, s1);
-            {   // the other half of this query's keys lives in lane ^ 32
+            if (__builtin_amdgcn_ballot_w64(first_tile || tmax > kRescaleThreshold) != 0) {
                 const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
                 tmax = vmax(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-            }
-            // both lanes of a query (r, r + 32) see the same tmax and m_run: same decision
-            const bool raise = first_tile || tmax > kRescaleThreshold;
-            if (__builtin_amdgcn_ballot_w64(raise) != 0) {
+                // both lanes of a query (r, r + 32) now hold the same tmax and m_run: same decision
+                const bool raise = first_tile || tmax > kRescaleThreshold;
                 const float delta = raise ? tmax : 0.f;
                 const float alpha = first_tile ? 1.f : __builtin_amdgcn_exp2f(-delta);   // O and sums are 0 at first
                 m_run += delta;
