@@ -18,7 +18,7 @@ rows = (batch * t_pad + 255) // 256 * 256
 qkv = torch.randn((rows, 3 * d), generator=g)
 qkv[:, :d] *= 1.4426950408889634 / math.sqrt(head)   # the kernel takes q in log2 units
 qkv = qkv.to(torch.bfloat16).to(dev)
-emb = torch.zeros((96, head)); emb[:73] = torch.randn((73, head), generator=g) * (8.0 / math.sqrt(head))
+emb = torch.zeros((96, head)); emb[:73] = torch.randn((73, head), generator=g)
 emb = emb.to(torch.bfloat16).to(dev)
 lens = torch.full((batch,), T, dtype=torch.int32, device=dev)
 ctx = torch.zeros((rows, d), dtype=torch.bfloat16, device=dev)

@@ -12,7 +12,12 @@ targets = {"ffn_up": "gemm_bf16_kernel<1", "ffn_down": "gemm_bf16_kernel<3", "dx
 table = collections.OrderedDict()
 for name, needle in targets.items():
     acc = collections.defaultdict(list)
+    newest = {}   # one file per pass directory: results of earlier runs merged into the same tree are skipped
     for f in glob.glob(os.path.join(root, name + "_p*", "**", "*counter_collection.csv"), recursive=True):
+        key = os.path.relpath(f, root).split(os.sep)[0]
+        if key not in newest or os.path.getmtime(f) > os.path.getmtime(newest[key]):
+            newest[key] = f
+    for f in newest.values():
         for r in csv.DictReader(open(f)):
             if needle in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
