@@ -75,14 +75,26 @@ __global__ __launch_bounds__(128 * VPL) void dwconv_ln_swish_kernel(
     const int b = item / t_tiles, t0 = (item % t_tiles) * kTimeTile;
     const int c = threadIdx.x * 2;
     const uint16_t* xb = x + (int64_t)b * t_pad * D + c;
+    // Only the first tiles of an utterance have rows before its start: every other tile loads its
+    // kRows rows without a test per row.
+    uint32_t raw[kRows];
+    if (t0 >= K - 1) {
+        const uint16_t* xt = xb + (int64_t)(t0 - (K - 1)) * D;
+#pragma unroll
+        for (int i = 0; i < kRows; ++i) raw[i] = *reinterpret_cast<const uint32_t*>(xt + (int64_t)i * D);
+    } else {
+#pragma unroll
+        for (int i = 0; i < kRows; ++i) {
+            const int t = t0 - (K - 1) + i;
+            raw[i] = 0;
+            if (t >= 0) raw[i] = *reinterpret_cast<const uint32_t*>(xb + (int64_t)t * D);
+        }
+    }
     float in0[kRows], in1[kRows];
 #pragma unroll
     for (int i = 0; i < kRows; ++i) {
-        const int t = t0 - (K - 1) + i;
-        uint32_t v = 0;
-        if (t >= 0) v = *reinterpret_cast<const uint32_t*>(xb + (int64_t)t * D);
-        in0[i] = __uint_as_float(v << 16);
-        in1[i] = __uint_as_float(v & 0xFFFF0000u);
+        in0[i] = __uint_as_float(raw[i] << 16);
+        in1[i] = __uint_as_float(raw[i] & 0xFFFF0000u);
     }
     float a0[kTimeTile], a1[kTimeTile];
 #pragma unroll
