@@ -26,14 +26,24 @@ __global__ __launch_bounds__(256) void dwconv_causal_kernel(const uint16_t* __re
     const int t0 = blockIdx.x * kTimeTile;
     const int c = (blockIdx.y * 256 + threadIdx.x) * 2;
     const uint16_t* xb = x + (int64_t)b * t_pad * d + c;
+    uint32_t raw[kRows];
+    if (t0 >= K - 1) {   // no row before the utterance start: no test per row
+        const uint16_t* xt = xb + (int64_t)(t0 - (K - 1)) * d;
+#pragma unroll
+        for (int i = 0; i < kRows; ++i) raw[i] = *reinterpret_cast<const uint32_t*>(xt + (int64_t)i * d);
+    } else {
+#pragma unroll
+        for (int i = 0; i < kRows; ++i) {
+            const int t = t0 - (K - 1) + i;
+            raw[i] = 0;
+            if (t >= 0) raw[i] = *reinterpret_cast<const uint32_t*>(xb + (int64_t)t * d);
+        }
+    }
     float in0[kRows], in1[kRows];
 #pragma unroll
     for (int i = 0; i < kRows; ++i) {
-        const int t = t0 - (K - 1) + i;
-        uint32_t v = 0;
-        if (t >= 0) v = *reinterpret_cast<const uint32_t*>(xb + (int64_t)t * d);
-        in0[i] = __uint_as_float(v << 16);
-        in1[i] = __uint_as_float(v & 0xFFFF0000u);
+        in0[i] = __uint_as_float(raw[i] << 16);
+        in1[i] = __uint_as_float(raw[i] & 0xFFFF0000u);
     }
     float a0[kTimeTile], a1[kTimeTile];
 #pragma unroll
