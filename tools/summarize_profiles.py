@@ -64,7 +64,11 @@ KB = 1024.0
 for kind, substr, key, shape, algo in (
         ("gemm", "gemm_bf16_kernel<1", "gemm_bf16_kernel<1>", "48128x4096x1024",
          48128 * 1024 * 2 + 4096 * 1024 * 2 + 4096 * 4 + 48128 * 4096 * 2),
-        ("logmel", "logmel_kernel", "logmel_kernel", "32x480000", 32 * (480000 * 4 + 2998 * 80 * 4))):
+        ("logmel", "logmel_kernel", "logmel_kernel", "32x480000", 32 * (480000 * 4 + 2998 * 80 * 4)),
+        # the two small kernels after it: per-utterance statistics (32 x 8 partial blocks x 160 floats in, 160 out)
+        # and normalise + stack (log-mel in, stacked float32 features [1504][160] out)
+        ("logmel", "stats_finalize_kernel", "stats_finalize_kernel", "32 utterances", 32 * (8 * 160 * 4 + 160 * 4)),
+        ("logmel", "norm_stack_kernel", "norm_stack_kernel", "32x2998x80", 32 * (2998 * 80 * 4 + 1504 * 160 * 4))):
     fetch = counter(kind, "FETCH_SIZE", substr)
     write = counter(kind, "WRITE_SIZE", substr)
     if fetch is None or write is None:
