@@ -264,7 +264,7 @@ def part_a() -> dict:
 # ----------------------------------------------------------------------------------------------------
 # Part B
 
-def part_b(only_device_fixture: bool = False) -> dict:
+def part_b(only_device_fixture: bool = False, only_logmel: bool = False) -> dict:
     import torch
     from transformers import SeamlessM4TFeatureExtractor, Wav2Vec2BertConfig, Wav2Vec2BertModel
 
@@ -279,6 +279,11 @@ def part_b(only_device_fixture: bool = False) -> dict:
         waves = {"noise_1s": (0.1 * rng.standard_normal(16000)).astype(np.float32),
                  "tone_odd": (0.3 * np.sin(2 * np.pi * 523.25 * np.arange(16400) / 16000.0)
                               + 0.01 * rng.standard_normal(16400)).astype(np.float32)}
+        # real speech: the first 6 s of the reference's sample file (BASELINE config 1), decoded and resampled
+        # to 16 kHz by this package's host path (pauses reach the log floor, which noise and tones do not)
+        sys.path.insert(0, str(ROOT / "omnilingual-asr_amd"))
+        from omnilingual_asr import audio as host_audio
+        waves["speech_6s"] = np.ascontiguousarray(host_audio.load_audio_16k(GOLDEN / "gettysburg.wav")[:96000], dtype=np.float32)
         store = {}
         for name, wav in waves.items():
             enc = fe(wav, sampling_rate=16000, return_tensors="np")
@@ -294,6 +299,8 @@ def part_b(only_device_fixture: bool = False) -> dict:
                           "max_abs_diff_logmel": float(np.abs(OL.logmel(wav) - raw).max()),
                           "max_abs_diff_features": float(np.abs(mine[:n] - feats[:n]).max())}
         np.savez_compressed(GOLDEN / "standin_logmel.npz", **store)
+        if only_logmel:
+            return info
 
     def convert(model, n_layers):
         sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
@@ -398,6 +405,14 @@ def main():
         info.update(part_b(only_device_fixture=True))
         info_path.write_text(json.dumps(info, indent=1, sort_keys=True) + "\n")
         print(json.dumps(info["encoder_device_width"], indent=1))
+        return
+    if "--logmel-fixture" in sys.argv:
+        # only standin_logmel.npz (the encoder fixtures and the reference-derived ones stay as they are)
+        info_path = GOLDEN / "standin_info.json"
+        info = json.loads(info_path.read_text())
+        info.update(part_b(only_logmel=True))
+        info_path.write_text(json.dumps(info, indent=1, sort_keys=True) + "\n")
+        print(json.dumps({k: info[k] for k in ("noise_1s", "tone_odd", "speech_6s")}, indent=1))
         return
     a = part_a()
     (GOLDEN / "reference_host.json").write_text(json.dumps(a, indent=1, sort_keys=True) + "\n")

@@ -29,7 +29,7 @@ def load_standin_weights(z):
     return w
 
 
-@pytest.mark.parametrize("name", ["noise_1s", "tone_odd"])
+@pytest.mark.parametrize("name", ["noise_1s", "tone_odd", "speech_6s"])
 def test_logmel_kernels_match_the_standin_vectors(golden_dir, name):
     """PCM of the fixture through oasr_logmel_f32 + oasr_feature_norm_stack; tolerances of the device
     feature tests: log-mel 2e-3, normalised stacked features 5e-3 (absolute)."""

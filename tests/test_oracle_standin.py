@@ -16,7 +16,7 @@ def lm(golden_dir):
     return np.load(golden_dir / "standin_logmel.npz")
 
 
-@pytest.mark.parametrize("name", ["noise_1s", "tone_odd"])
+@pytest.mark.parametrize("name", ["noise_1s", "tone_odd", "speech_6s"])
 def test_logmel_matches_standin(lm, name):
     pcm = lm[name + "_pcm"]
     raw, feats, mask = lm[name + "_logmel"], lm[name + "_features"], lm[name + "_mask"]
