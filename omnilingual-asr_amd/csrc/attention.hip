@@ -21,6 +21,8 @@
 // scores are rescaled) only when some score exceeds it by more than a threshold.
 // The relative-key term needs only the L+R+1 distinct values q_i . E[c]: they are computed once per
 // wave by MFMA into LDS; key tiles entirely left (right) of the clamp window use one register value.
+// A wave's copies of the next key tile are issued between the MFMA pairs of S^T (their issue time is then
+// covered by the matrix pipe), and its finished output tile crosses LDS once so that it is stored as whole rows.
 #include <type_traits>
 
 #include "oasr_common.h"
