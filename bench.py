@@ -131,8 +131,8 @@ def kernel_rooflines(engine, batch: int, t_pad: int, pcm, nv, hidden) -> dict:
                 _hip.check(L.oasr_gemm_fp8(a8.data_ptr(), lw[wname + "_q"].data_ptr(), sa.data_ptr(),
                                            lw[wname + "_s"].data_ptr(), bias, res, c.data_ptr(), rows, n, k, alpha, epi, st))
             else:
-                _hip.check(L.oasr_gemm_bf16(a.data_ptr(), lw[wname].data_ptr(), bias, res, c.data_ptr(), rows, n, k,
-                                            alpha, epi, st))
+                fn = L.oasr_gemm_bf16_pw if engine._packed["gemm_weights_packed"] else L.oasr_gemm_bf16
+                _hip.check(fn(a.data_ptr(), lw[wname].data_ptr(), bias, res, c.data_ptr(), rows, n, k, alpha, epi, st))
         return run
 
     def quant(a, k):   # fp8: the row quantiser that feeds a projection whose input a GEMM / attention produced

@@ -181,6 +181,10 @@ typedef struct oasr_layer_fp8_weights {
     const uint8_t* ffn2_w2_q; const float* ffn2_w2_s;
 } oasr_layer_fp8_weights;
 int oasr_encoder_set_fp8(oasr_encoder* enc, const oasr_layer_fp8_weights* layers);
+/* Declares that every bf16 projection matrix handed to oasr_encoder_create (fp_w and the eight per layer:
+ * ffn1_w1, ffn1_w2, wqkv, wo, pw1, pw2, ffn2_w1, ffn2_w2) is in the packed layout of oasr_gemm_pack_w_bf16
+ * (packed != 0) or row-major (0, the default).  Same results either way; packed copies faster. */
+int oasr_encoder_set_packed_weights(oasr_encoder* enc, int32_t packed);
 
 /* Rows of the activation matrices for a batch: round_up(batch * t_pad, 256). */
 int64_t oasr_encoder_rows(int32_t batch, int64_t t_pad);
@@ -228,6 +232,16 @@ typedef enum oasr_epilogue {
 int oasr_gemm_bf16(const uint16_t* a, const uint16_t* w, const float* bias, const float* resid,
                    void* c, int64_t m, int64_t n, int64_t k, float alpha, int32_t epilogue,
                    void* stream);
+
+/* The same product with the weights in the packed layout the kernel copies fastest: W cut into pieces of
+ * 16 rows x 32 k (1 KiB, stored as the kernel's LDS image of that piece), ordered [row group][k slice].
+ * oasr_gemm_pack_w_bf16 makes that layout from row-major W[n][k] (n a multiple of 16, k of 32; out must
+ * not alias w); results are bit-identical to oasr_gemm_bf16 on the row-major matrix.  Part of the
+ * encoder (no counterpart in the reference): see oasr_encoder_set_packed_weights. */
+int oasr_gemm_pack_w_bf16(const uint16_t* w, int64_t n, int64_t k, uint16_t* out, void* stream);
+int oasr_gemm_bf16_pw(const uint16_t* a, const uint16_t* w_packed, const float* bias, const float* resid,
+                      void* c, int64_t m, int64_t n, int64_t k, float alpha, int32_t epilogue,
+                      void* stream);
 
 /* FLAC decode on the host (the reference accepts .flac uploads and forwards the bytes to its remote
  * model: ref gemini_pipeline.py:106-118, workflows/wav2elan_web/app.py:76-77).  oasr_flac_info reads

@@ -11,6 +11,7 @@ struct oasr_encoder {
     oasr_top_weights top;
     std::vector<oasr_layer_weights> layers;
     std::vector<oasr_layer_fp8_weights> fp8;   // empty: bf16 projections
+    bool packed_w = false;                      // bf16 projection matrices in the layout of oasr_gemm_pack_w_bf16
 };
 
 namespace oasr {
@@ -106,6 +107,12 @@ int oasr_encoder_set_fp8(oasr_encoder* enc, const oasr_layer_fp8_weights* layers
     return OASR_OK;
 }
 
+int oasr_encoder_set_packed_weights(oasr_encoder* enc, int32_t packed) {
+    OASR_REQUIRE(enc, "encoder_set_packed_weights: null handle");
+    enc->packed_w = packed != 0;
+    return OASR_OK;
+}
+
 void oasr_encoder_destroy(oasr_encoder* enc) { delete enc; }
 
 int64_t oasr_encoder_rows(int32_t batch, int64_t t_pad) { return round_up((int64_t)batch * t_pad, 256); }
@@ -139,13 +146,13 @@ int oasr_encoder_forward(const oasr_encoder* enc, const float* feats, const int3
     // input projection: LayerNorm(160) -> bf16 [rows][192] -> Linear -> x
     OASR_TRY(oasr_layernorm(feats, enc->top.fp_ln_w, enc->top.fp_ln_b, ws.big, live, OASR_FEAT_DIM, kFeatK,
                             c.ln_eps, 1, 0, stream));
-    OASR_TRY(oasr_gemm_bf16(ws.big, enc->top.fp_w, enc->top.fp_b, nullptr, x, rows, d, kFeatK, 1.0f,
-                            OASR_EPI_BIAS_F32, stream));
+    auto gemm = enc->packed_w ? oasr_gemm_bf16_pw : oasr_gemm_bf16;   // same signature, weights packed or row-major
+    OASR_TRY(gemm(ws.big, enc->top.fp_w, enc->top.fp_b, nullptr, x, rows, d, kFeatK, 1.0f, OASR_EPI_BIAS_F32, stream));
     // one large projection: bf16 GEMM, or row quantisation + fp8 GEMM when fp8 weights are set
     // `a` = nullptr: the operand already sits in ws.a8 / ws.sa (written by a LayerNorm of the fp8 path)
     auto project = [&](const uint16_t* a, int64_t k, const uint16_t* wb, const uint8_t* wq, const float* wscale,
                        const float* bias, const float* resid, void* dst, int64_t n, float alpha, int epi) -> int {
-        if (!fp8) return oasr_gemm_bf16(a, wb, bias, resid, dst, rows, n, k, alpha, epi, stream);
+        if (!fp8) return gemm(a, wb, bias, resid, dst, rows, n, k, alpha, epi, stream);
         if (a) OASR_TRY(oasr_quant_fp8_rows(a, rows, k, ws.a8, ws.sa, stream));
         return oasr_gemm_fp8(ws.a8, wq, ws.sa, wscale, bias, resid, dst, rows, n, k, alpha, epi, stream);
     };

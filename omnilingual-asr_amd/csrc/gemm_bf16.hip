@@ -6,6 +6,10 @@
 // The LDS image is lane-linear per wave instruction (16 rows x 64 bytes), so the bank-conflict
 // swizzle (16-byte chunk index XOR (-(row >> 2) & 3)) is applied to the per-lane *source* address
 // and again on the fragment read (conflict-free ds_read_b128).
+// Weights may also be given "packed" (oasr_gemm_pack_w_bf16): every 1 KiB piece of that LDS image (16 rows x
+// one K slice, swizzle applied) stored contiguously, pieces ordered [row group][K slice].  A copy
+// instruction then reads 8 whole cache lines instead of 16 half lines: 6 % off the 48128 x 4096 x 1024
+// product, bit-identical results (the LDS image is the same).
 //
 // Tile and waves.  256 x 256 output tile, 8 wavefronts as 2 (m) x 4 (n); a wave owns 128 m x 64 n
 // as 8 x 4 tiles of v_mfma_f32_16x16x32_bf16.  The weight fragment is the MFMA's A operand and the
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(const uint16_t* __restri
                                                         const uint16_t* __restrict__ W,
                                                         const float* __restrict__ bias,
                                                         const float* resid, void* C, int64_t N,
-                                                        int64_t K, float alpha, int n_tiles) {
+                                                        int64_t K, float alpha, int n_tiles, int w_packed) {
     // ONE object on purpose: with the ring in an array of its own the compiler orders every fragment
     // read after all copies in flight (s_waitcnt vmcnt(0) per slice), which serialises the ring
     __shared__ __attribute__((aligned(1024))) char smem[2 * kRing * kSliceBytes + 8 * kEpiSlab + 8 * 2 * 256];  // A ring | W ring | slabs | bias strips
@@ -281,19 +285,23 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(const uint16_t* __restri
     const uint32_t lane_off =
         (uint32_t)(((lane >> 2) * K + (((lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3)) << 3)) * 2);
     const int64_t piece_stride = 16 * K * 2;
+    // packed weights: piece (row group g, slice t) lies at ((g * nph) + t) KiB, lanes in order
+    const uint32_t lane_off_w = w_packed ? (uint32_t)lane * 16 : lane_off;
+    const int64_t piece_stride_w = w_packed ? (int64_t)nph * 1024 : piece_stride;
+    const int w_step = w_packed ? 1024 : BK * 2;
     int st_i = 0, st_t = 0;
     const char *st_a, *st_w;
     auto stage_seek = [&](int i) {
         int64_t m0, n0;
         tile_origin(i, m0, n0);
         st_a = reinterpret_cast<const char*>(A) + (m0 + wave * 32) * K * 2;
-        st_w = reinterpret_cast<const char*>(W) + (n0 + wave * 32) * K * 2;
+        st_w = reinterpret_cast<const char*>(W) + (w_packed ? ((n0 + wave * 32) >> 4) * (int64_t)nph * 1024 : (n0 + wave * 32) * K * 2);
     };
     auto stage_next = [&](int p) {  // global phase p = st_i * nph + st_t  ->  ring slot p & 3
         stage_slice(st_a, lane_off, piece_stride, smem + (p & 3) * kSliceBytes, wave);
-        stage_slice(st_w, lane_off, piece_stride, smem + (kRing + (p & 3)) * kSliceBytes, wave);
+        stage_slice(st_w, lane_off_w, piece_stride_w, smem + (kRing + (p & 3)) * kSliceBytes, wave);
         st_a += BK * 2;
-        st_w += BK * 2;
+        st_w += w_step;
         if (++st_t == nph) {
             st_t = 0;
             if (++st_i < my_tiles) stage_seek(st_i);
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_small_kernel(const uint16_t*
                                                                  const uint16_t* __restrict__ W,
                                                                  const float* __restrict__ bias, const float* resid,
                                                                  void* C, int64_t N, int64_t K, float alpha,
-                                                                 int tiles_m, int n_tiles) {
+                                                                 int tiles_m, int n_tiles, int w_packed) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * kRing * kSmallSlice + 4 * kEpiSlab];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -434,13 +442,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_small_kernel(const uint16_t*
     const uint32_t lane_off =
         (uint32_t)(((lane >> 2) * K + (((lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3)) << 3)) * 2);
     const int64_t piece_stride = 16 * K * 2;
+    const uint32_t lane_off_w = w_packed ? (uint32_t)lane * 16 : lane_off;
+    const int64_t piece_stride_w = w_packed ? (int64_t)nph * 1024 : piece_stride;
+    const int w_step = w_packed ? 1024 : BK * 2;
     const char* st_a = reinterpret_cast<const char*>(A) + (m0 + wave * 32) * K * 2;
-    const char* st_w = reinterpret_cast<const char*>(W) + (n0 + wave * 32) * K * 2;
+    const char* st_w = reinterpret_cast<const char*>(W) + (w_packed ? ((n0 + wave * 32) >> 4) * (int64_t)nph * 1024 : (n0 + wave * 32) * K * 2);
     auto stage_next = [&](int p) {
         stage_slice(st_a, lane_off, piece_stride, smem + (p & 3) * kSmallSlice, wave);
-        stage_slice(st_w, lane_off, piece_stride, smem + (kRing + (p & 3)) * kSmallSlice, wave);
+        stage_slice(st_w, lane_off_w, piece_stride_w, smem + (kRing + (p & 3)) * kSmallSlice, wave);
         st_a += BK * 2;
-        st_w += BK * 2;
+        st_w += w_step;
     };
     stage_next(0);
     if (nph > 1) {
@@ -477,13 +488,28 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_small_kernel(const uint16_t*
                           smem + 2 * kRing * kSmallSlice + wave * kEpiSlab);
 }
 
+// Row-major bf16 weights [n][k] -> the packed form read by the kernels above: one thread per 16-byte chunk;
+// chunk `lane` of piece (row group g, K slice t) is row 16 g + (lane >> 2), source chunk
+// (lane & 3) ^ (-(row >> 2) & 3) of the slice, as lane_off places it.
+__global__ __launch_bounds__(256) void gemm_pack_w_kernel(const uint16_t* __restrict__ w, uint16_t* __restrict__ out,
+                                                          int64_t n, int64_t k) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;   // 16-byte chunk of the output
+    const int64_t nph = k / BK, total = (n / 16) * nph * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const int64_t piece = idx >> 6, g = piece / nph, t = piece - g * nph;
+    const int row = lane >> 2, chunk = (lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(w + (g * 16 + row) * k + t * BK + chunk * 8);
+    *reinterpret_cast<u32x4*>(out + idx * 8) = v;
+}
+
 }  // namespace oasr
 
 using namespace oasr;
 
-extern "C" int oasr_gemm_bf16(const uint16_t* a, const uint16_t* w, const float* bias,
-                              const float* resid, void* c, int64_t m, int64_t n, int64_t k,
-                              float alpha, int32_t epilogue, void* stream) {
+static int gemm_bf16_launch(const uint16_t* a, const uint16_t* w, const float* bias, const float* resid, void* c,
+                            int64_t m, int64_t n, int64_t k, float alpha, int32_t epilogue, void* stream,
+                            int w_packed) {
     OASR_REQUIRE(a && w && c, "gemm: null pointer");
     OASR_REQUIRE(m > 0 && n > 0 && k > 0 && m % BM == 0 && n % BN == 0 && k % BK == 0,
                  "gemm: m=%lld n=%lld must be multiples of 256 and k=%lld of 32", (long long)m,
@@ -499,7 +525,7 @@ extern "C" int oasr_gemm_bf16(const uint16_t* a, const uint16_t* w, const float*
         const int tm = (int)(m / kSmallTile), nt = tm * (int)(n / kSmallTile);
         hipStream_t st = (hipStream_t)stream;
 #define OASR_LAUNCH_SMALL(E) \
-    hipLaunchKernelGGL((gemm_bf16_small_kernel<E>), dim3((unsigned)nt), dim3(256), 0, st, a, w, bias, resid, c, n, k, alpha, tm, nt)
+    hipLaunchKernelGGL((gemm_bf16_small_kernel<E>), dim3((unsigned)nt), dim3(256), 0, st, a, w, bias, resid, c, n, k, alpha, tm, nt, w_packed)
         switch (epilogue) {
             case OASR_EPI_BIAS_BF16: OASR_LAUNCH_SMALL(OASR_EPI_BIAS_BF16); break;
             case OASR_EPI_BIAS_SWISH_BF16: OASR_LAUNCH_SMALL(OASR_EPI_BIAS_SWISH_BF16); break;
@@ -521,9 +547,9 @@ extern "C" int oasr_gemm_bf16(const uint16_t* a, const uint16_t* w, const float*
 #define OASR_LAUNCH_GEMM(E)                                                                                          \
     do {                                                                                                             \
         if (k >= 2048)                                                                                               \
-            hipLaunchKernelGGL((gemm_bf16_kernel<E, true>), grid, blk, 0, st, a, w, bias, resid, c, n, k, alpha, tiles);  \
+            hipLaunchKernelGGL((gemm_bf16_kernel<E, true>), grid, blk, 0, st, a, w, bias, resid, c, n, k, alpha, tiles, w_packed);  \
         else                                                                                                         \
-            hipLaunchKernelGGL((gemm_bf16_kernel<E, false>), grid, blk, 0, st, a, w, bias, resid, c, n, k, alpha, tiles); \
+            hipLaunchKernelGGL((gemm_bf16_kernel<E, false>), grid, blk, 0, st, a, w, bias, resid, c, n, k, alpha, tiles, w_packed); \
     } while (0)
     switch (epilogue) {
         case OASR_EPI_BIAS_BF16: OASR_LAUNCH_GEMM(OASR_EPI_BIAS_BF16); break;
@@ -537,5 +563,29 @@ extern "C" int oasr_gemm_bf16(const uint16_t* a, const uint16_t* w, const float*
     }
 #undef OASR_LAUNCH_GEMM
     OASR_CHECK_LAUNCH("gemm");
+    return OASR_OK;
+}
+
+extern "C" int oasr_gemm_bf16(const uint16_t* a, const uint16_t* w, const float* bias,
+                              const float* resid, void* c, int64_t m, int64_t n, int64_t k,
+                              float alpha, int32_t epilogue, void* stream) {
+    return gemm_bf16_launch(a, w, bias, resid, c, m, n, k, alpha, epilogue, stream, 0);
+}
+
+extern "C" int oasr_gemm_bf16_pw(const uint16_t* a, const uint16_t* w_packed, const float* bias,
+                                 const float* resid, void* c, int64_t m, int64_t n, int64_t k,
+                                 float alpha, int32_t epilogue, void* stream) {
+    return gemm_bf16_launch(a, w_packed, bias, resid, c, m, n, k, alpha, epilogue, stream, 1);
+}
+
+extern "C" int oasr_gemm_pack_w_bf16(const uint16_t* w, int64_t n, int64_t k, uint16_t* out, void* stream) {
+    OASR_REQUIRE(w && out && w != out, "gemm_pack_w: null pointer or in-place call");
+    OASR_REQUIRE(n > 0 && k > 0 && n % 16 == 0 && k % BK == 0, "gemm_pack_w: n=%lld must be a multiple of 16 and k=%lld of 32",
+                 (long long)n, (long long)k);
+    OASR_REQUIRE(((uintptr_t)w & 15) == 0 && ((uintptr_t)out & 15) == 0, "gemm_pack_w: operands must be 16-byte aligned");
+    const int64_t chunks = n * k / 8;
+    OASR_REQUIRE(chunks / 256 + 1 < ((int64_t)1 << 31), "gemm_pack_w: matrix too large");
+    hipLaunchKernelGGL(gemm_pack_w_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, out, n, k);
+    OASR_CHECK_LAUNCH("gemm_pack_w");
     return OASR_OK;
 }

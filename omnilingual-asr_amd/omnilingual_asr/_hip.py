@@ -86,6 +86,9 @@ _SIGNATURES = {
     "oasr_layernorm": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_f32, c_i32, c_i32, c_vp]),
     "oasr_layernorm2": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_vp]),
     "oasr_gemm_bf16": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_i32, c_vp]),
+    "oasr_gemm_bf16_pw": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_i32, c_vp]),
+    "oasr_gemm_pack_w_bf16": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp]),
+    "oasr_encoder_set_packed_weights": (c_i32, [c_vp, c_i32]),
     "oasr_encoder_set_fp8": (c_i32, [c_vp, c_vp]),
     "oasr_layernorm_fp8": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_i32, c_vp]),
     "oasr_layernorm2_fp8": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_vp]),

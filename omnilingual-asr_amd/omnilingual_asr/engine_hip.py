@@ -9,6 +9,7 @@ not re-entrant: callers serialise `encode_batch` (the pipeline holds a lock).
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -39,6 +40,9 @@ class HipEngine:
             weights = init_random_weights(g, seed)
         self.fp8 = bool(fp8)    # e4m3 weights + per-row quantised activations in the eight large projections
         self._packed = pack_for_device(weights, g, self.device, fp8=self.fp8)   # keeps device buffers alive
+        self._packed["gemm_weights_packed"] = False
+        if not os.environ.get("OASR_ROWMAJOR_WEIGHTS"):   # A/B switch: keep the projection matrices row-major
+            self._pack_gemm_weights()
         self._tables = torch.from_numpy(_hip.logmel_table_blob().view(np.int32)).to(self.device)
         self._handle = self._create_handle()
         self._buffers: dict = {}
@@ -51,6 +55,30 @@ class HipEngine:
         self.max_buffer_sets = 6        # distinct (batch, padded length) shapes kept resident
 
     # ---- set-up ---------------------------------------------------------------------------------------
+    GEMM_WEIGHTS = ("ffn1_w1", "ffn1_w2", "wqkv", "wo", "pw1", "pw2", "ffn2_w1", "ffn2_w2")
+
+    def _pack_gemm_weights(self):
+        """Every bf16 projection matrix goes into the GEMM kernel's packed layout (1 KiB pieces of 16 rows x 32 k
+        in the order the kernel copies them: `oasr_gemm_pack_w_bf16`); the row-major copies are dropped."""
+        L = _hip.lib()
+        with torch.cuda.device(self.device):
+            st = _hip.current_stream_ptr()
+
+            def packed(w):
+                out = torch.empty_like(w)
+                _hip.check(L.oasr_gemm_pack_w_bf16(w.data_ptr(), w.shape[0], w.shape[1], out.data_ptr(), st),
+                           "oasr_gemm_pack_w_bf16")
+                return out
+
+            self._packed["top"]["fp_w"] = packed(self._packed["top"]["fp_w"])
+            for layer in self._packed["layers"]:
+                for name in self.GEMM_WEIGHTS:
+                    layer[name] = packed(layer[name])
+            if "ctc_w" in self._packed:
+                self._packed["ctc_w"] = packed(self._packed["ctc_w"])
+            torch.cuda.synchronize()
+        self._packed["gemm_weights_packed"] = True
+
     def _create_handle(self):
         g = self.geometry
         cfg = _hip.EncoderConfig(g.feat_dim, g.d_model, g.ffn_dim, g.n_heads, g.n_layers,
@@ -63,6 +91,8 @@ class HipEngine:
         handle = C.c_void_p()
         _hip.check(_hip.lib().oasr_encoder_create(C.byref(cfg), C.byref(top), arr, C.byref(handle)),
                    "oasr_encoder_create")
+        _hip.check(_hip.lib().oasr_encoder_set_packed_weights(handle, int(self._packed["gemm_weights_packed"])),
+                   "oasr_encoder_set_packed_weights")
         if self.fp8:
             q = (_hip.LayerFp8Weights * max(1, g.n_layers))()
             for i, L in enumerate(self._packed["layers"]):
@@ -206,7 +236,8 @@ class HipEngine:
         if hidden.data_ptr() != buf["out"].data_ptr():
             buf["out"][: batch * t_pad].copy_(hidden.reshape(batch * t_pad, d))
         _hip.check(L.oasr_cast_bf16(buf["out"].data_ptr(), buf["hid_bf16"].data_ptr(), rows * d, st), "oasr_cast_bf16")
-        _hip.check(L.oasr_gemm_bf16(buf["hid_bf16"].data_ptr(), self._packed["ctc_w"].data_ptr(),
+        gemm = L.oasr_gemm_bf16_pw if self._packed["gemm_weights_packed"] else L.oasr_gemm_bf16
+        _hip.check(gemm(buf["hid_bf16"].data_ptr(), self._packed["ctc_w"].data_ptr(),
                                     self._packed["ctc_b"].data_ptr(), None, buf["logits"].data_ptr(), rows,
                                     CTC_LOGIT_PITCH, d, 1.0, _hip.EPI_BIAS_F32, st), "oasr_gemm_bf16 (ctc)")
         _hip.check(L.oasr_ctc_greedy(buf["logits"].data_ptr(), CTC_LOGIT_PITCH, self.geometry.vocab_size,

@@ -445,3 +445,42 @@ def test_dwconv_ln_swish_fused(batch, t_pad, d):
     ref = torch.nn.functional.layer_norm(conv, (d,), ln_w.double(), ln_b.double(), 1e-5)
     ref = ref * torch.sigmoid(ref)
     torch.testing.assert_close(y.float().cpu().double().reshape(batch, t_pad, d), ref, atol=2e-2, rtol=1e-2)
+
+
+def _pack_w_reference(w: torch.Tensor) -> torch.Tensor:
+    """The packed weight layout restated with tensor operations: pieces of 16 rows x 32 k ordered
+    [row group][k slice]; inside a piece, 16-byte chunk `pos` of row r holds source chunk pos ^ (-(r >> 2) & 3)."""
+    n, k = w.shape
+    v = w.view(n // 16, 16, k // 32, 4, 8).permute(0, 2, 1, 3, 4)            # [group][slice][row][chunk][8]
+    rows = torch.arange(16).view(16, 1)
+    src = torch.arange(4).view(1, 4) ^ ((4 - ((rows >> 2) & 3)) & 3)          # [row][pos] -> source chunk
+    return v[:, :, rows, src].reshape(n, k).contiguous()
+
+
+@pytest.mark.parametrize("m,n,k,epi", [(4352, 4096, 1024, 1), (4352, 1024, 4096, 3), (768, 512, 64, 0),
+                                       (2304, 2048, 96, 2), (48128, 1024, 192, 4)])
+def test_gemm_packed_weights_equal_row_major_bit_for_bit(m, n, k, epi):
+    """oasr_gemm_pack_w_bf16 against its restatement, and oasr_gemm_bf16_pw on the packed matrix against
+    oasr_gemm_bf16 on the row-major one: both tile sizes, every epilogue, one to 128 K slices."""
+    H = _lib()
+    g = torch.Generator().manual_seed(m + n + k)
+    a = _bf(torch.randn((m, k), generator=g)).cuda()
+    w = _bf(torch.randn((n, k), generator=g) / math.sqrt(k))
+    wd = w.cuda()
+    wp = torch.empty_like(wd)
+    H.check(H.lib().oasr_gemm_pack_w_bf16(wd.data_ptr(), n, k, wp.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(wp.cpu().view(torch.int16), _pack_w_reference(w).view(torch.int16))
+    bias = None if epi == 2 else torch.randn((n,), generator=g).cuda()
+    resid = torch.randn((m, n), generator=g).cuda() if epi == 3 else None
+    odt = torch.float32 if epi in (3, 4) else torch.bfloat16
+    outs = []
+    for fn, wmat in ((H.lib().oasr_gemm_bf16, wd), (H.lib().oasr_gemm_bf16_pw, wp)):
+        c = torch.zeros((m, n // 2 if epi == 2 else n), dtype=odt, device="cuda")
+        H.check(fn(a.data_ptr(), wmat.data_ptr(), None if bias is None else bias.data_ptr(),
+                   None if resid is None else resid.data_ptr(), c.data_ptr(), m, n, k, 0.5, epi, _stream()))
+        outs.append(c)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    assert H.lib().oasr_gemm_pack_w_bf16(wd.data_ptr(), n, k, wd.data_ptr(), _stream()) != 0      # in place: refused
+    assert H.lib().oasr_gemm_pack_w_bf16(wd.data_ptr(), n + 8, k, wp.data_ptr(), _stream()) != 0   # n not a multiple of 16
