@@ -242,6 +242,17 @@ int oasr_gemm_pack_w_bf16(const uint16_t* w, int64_t n, int64_t k, uint16_t* out
 int oasr_gemm_bf16_pw(const uint16_t* a, const uint16_t* w_packed, const float* bias, const float* resid,
                       void* c, int64_t m, int64_t n, int64_t k, float alpha, int32_t epilogue,
                       void* stream);
+/* The general form: any of the three matrices in the packed layout.  A packed: a[m][k] as made by
+ * oasr_gemm_pack_w_bf16(a, m, k) or by a product with OASR_GEMM_C_PACKED; C packed (epilogues
+ * OASR_EPI_BIAS_BF16 and OASR_EPI_BIAS_SWISH_BF16 only): c[m][n] is written in that layout, ready to be the
+ * next product's packed A.  Packed A pays when n is small (few column tiles share each copy of A):
+ * 48128 x 1024 x 4096 runs 7 % faster, 48128 x 4096 x 1024 no faster. */
+#define OASR_GEMM_W_PACKED 1
+#define OASR_GEMM_A_PACKED 2
+#define OASR_GEMM_C_PACKED 4
+int oasr_gemm_bf16_ex(const uint16_t* a, const uint16_t* w, const float* bias, const float* resid, void* c,
+                      int64_t m, int64_t n, int64_t k, float alpha, int32_t epilogue, int32_t flags,
+                      void* stream);
 
 /* FLAC decode on the host (the reference accepts .flac uploads and forwards the bytes to its remote
  * model: ref gemini_pipeline.py:106-118, workflows/wav2elan_web/app.py:76-77).  oasr_flac_info reads

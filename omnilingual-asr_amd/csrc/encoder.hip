@@ -146,13 +146,19 @@ int oasr_encoder_forward(const oasr_encoder* enc, const float* feats, const int3
     // input projection: LayerNorm(160) -> bf16 [rows][192] -> Linear -> x
     OASR_TRY(oasr_layernorm(feats, enc->top.fp_ln_w, enc->top.fp_ln_b, ws.big, live, OASR_FEAT_DIM, kFeatK,
                             c.ln_eps, 1, 0, stream));
-    auto gemm = enc->packed_w ? oasr_gemm_bf16_pw : oasr_gemm_bf16;   // same signature, weights packed or row-major
-    OASR_TRY(gemm(ws.big, enc->top.fp_w, enc->top.fp_b, nullptr, x, rows, d, kFeatK, 1.0f, OASR_EPI_BIAS_F32, stream));
+    const int wflag = enc->packed_w ? OASR_GEMM_W_PACKED : 0;   // projection matrices packed or row-major
+    OASR_TRY(oasr_gemm_bf16_ex(ws.big, enc->top.fp_w, enc->top.fp_b, nullptr, x, rows, d, kFeatK, 1.0f, OASR_EPI_BIAS_F32,
+                               wflag, stream));
+    // The FFN hidden activations go from the up-projection to the down-projection in the packed layout as
+    // well (bf16 path): the down-projection has only d / 256 column tiles to share each copy of its A
+    // operand, and a packed A makes those copies whole cache lines.
+    const int hid_out = fp8 ? 0 : OASR_GEMM_C_PACKED, hid_in = fp8 ? 0 : OASR_GEMM_A_PACKED;
     // one large projection: bf16 GEMM, or row quantisation + fp8 GEMM when fp8 weights are set
     // `a` = nullptr: the operand already sits in ws.a8 / ws.sa (written by a LayerNorm of the fp8 path)
     auto project = [&](const uint16_t* a, int64_t k, const uint16_t* wb, const uint8_t* wq, const float* wscale,
-                       const float* bias, const float* resid, void* dst, int64_t n, float alpha, int epi) -> int {
-        if (!fp8) return gemm(a, wb, bias, resid, dst, rows, n, k, alpha, epi, stream);
+                       const float* bias, const float* resid, void* dst, int64_t n, float alpha, int epi,
+                       int layout = 0) -> int {
+        if (!fp8) return oasr_gemm_bf16_ex(a, wb, bias, resid, dst, rows, n, k, alpha, epi, wflag | layout, stream);
         if (a) OASR_TRY(oasr_quant_fp8_rows(a, rows, k, ws.a8, ws.sa, stream));
         return oasr_gemm_fp8(ws.a8, wq, ws.sa, wscale, bias, resid, dst, rows, n, k, alpha, epi, stream);
     };
@@ -169,9 +175,9 @@ int oasr_encoder_forward(const oasr_encoder* enc, const float* feats, const int3
         if (l == 0) OASR_TRY(norm(x, w.ffn1_ln_w, w.ffn1_ln_b, rows, 0));
         // half-step feed-forward 1
         OASR_TRY(project(xn, d, w.ffn1_w1, q.ffn1_w1_q, q.ffn1_w1_s, w.ffn1_b1, nullptr, ws.big, f, 1.0f,
-                         OASR_EPI_BIAS_SWISH_BF16));
+                         OASR_EPI_BIAS_SWISH_BF16, hid_out));
         OASR_TRY(project(ws.big, f, w.ffn1_w2, q.ffn1_w2_q, q.ffn1_w2_s, w.ffn1_b2, x, x, d, 0.5f,
-                         OASR_EPI_RESIDUAL_F32));
+                         OASR_EPI_RESIDUAL_F32, hid_in));
         // self-attention
         OASR_TRY(norm(x, w.attn_ln_w, w.attn_ln_b, rows, 0));
         OASR_TRY(project(xn, d, w.wqkv, q.wqkv_q, q.wqkv_s, w.bqkv, nullptr, ws.big, 3 * (int64_t)d, 1.0f,
@@ -197,9 +203,9 @@ int oasr_encoder_forward(const oasr_encoder* enc, const float* feats, const int3
         // half-step feed-forward 2
         OASR_TRY(norm(x, w.ffn2_ln_w, w.ffn2_ln_b, rows, 0));
         OASR_TRY(project(xn, d, w.ffn2_w1, q.ffn2_w1_q, q.ffn2_w1_s, w.ffn2_b1, nullptr, ws.big, f, 1.0f,
-                         OASR_EPI_BIAS_SWISH_BF16));
+                         OASR_EPI_BIAS_SWISH_BF16, hid_out));
         OASR_TRY(project(ws.big, f, w.ffn2_w2, q.ffn2_w2_q, q.ffn2_w2_s, w.ffn2_b2, x, x, d, 0.5f,
-                         OASR_EPI_RESIDUAL_F32));
+                         OASR_EPI_RESIDUAL_F32, hid_in));
         // block output LayerNorm, fused with the next block's first LayerNorm when there is one
         if (l + 1 < nl) {
             const oasr_layer_weights& nx = enc->layers[l + 1];

@@ -120,11 +120,16 @@ __device__ __forceinline__ void bias_from_lds(f32x4 (&bv)[4], const char* strip,
 template <int EPI, int MI = 8>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][4],
                                               const float* resid, void* C, int64_t N, float alpha,
-                                              int64_t mbase, int64_t nbase, int lane, char* slab) {
+                                              int64_t mbase, int64_t nbase, int lane, char* slab, bool c_packed = false) {
     const int fr = lane & 15, fq = lane >> 4;
     if (EPI == OASR_EPI_BIAS_BF16 || EPI == OASR_EPI_BIAS_SWISH_BF16) {
         const int rrow = lane >> 3, rchunk = lane & 7;   // read-back role: rows rrow, rrow + 8; 16-byte chunk
         uint16_t* cbase = reinterpret_cast<uint16_t*>(C) + (mbase + rrow) * N + nbase + rchunk * 8;
+        // Packed output (the layout of oasr_gemm_pack_w_bf16, for a product that is the next one's A operand):
+        // a 16-row slice of the wave's 64 columns is two whole 1 KiB pieces; lane l stores position l of both,
+        // i.e. row l >> 2, source chunk (l & 3) ^ (-(row >> 2) & 3).
+        const int prow = lane >> 2, pchunk = (lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3);
+        char* pbase = reinterpret_cast<char*>(C) + ((mbase >> 4) * (N >> 5) + (nbase >> 5)) * 1024 + lane * 16;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -137,11 +142,20 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][4],
                     make_uint2(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]));
             }
             OASR_WAVE_LDS_SYNC();
-            const u32x4 lo = *reinterpret_cast<const u32x4*>(slab + rrow * kEpiPitch + rchunk * 16);
-            const u32x4 hi = *reinterpret_cast<const u32x4*>(slab + (rrow + 8) * kEpiPitch + rchunk * 16);
-            OASR_WAVE_LDS_SYNC();
-            store_nt16(cbase + (int64_t)(i * 16) * N, lo);
-            store_nt16(cbase + (int64_t)(i * 16 + 8) * N, hi);
+            if (c_packed) {   // wave-uniform
+                const u32x4 p0 = *reinterpret_cast<const u32x4*>(slab + prow * kEpiPitch + pchunk * 16);
+                const u32x4 p1 = *reinterpret_cast<const u32x4*>(slab + prow * kEpiPitch + 64 + pchunk * 16);
+                OASR_WAVE_LDS_SYNC();
+                char* dst = pbase + (int64_t)i * (N >> 5) * 1024;
+                store_nt16(dst, p0);
+                store_nt16(dst + 1024, p1);
+            } else {
+                const u32x4 lo = *reinterpret_cast<const u32x4*>(slab + rrow * kEpiPitch + rchunk * 16);
+                const u32x4 hi = *reinterpret_cast<const u32x4*>(slab + (rrow + 8) * kEpiPitch + rchunk * 16);
+                OASR_WAVE_LDS_SYNC();
+                store_nt16(cbase + (int64_t)(i * 16) * N, lo);
+                store_nt16(cbase + (int64_t)(i * 16 + 8) * N, hi);
+            }
         }
     } else if (EPI == OASR_EPI_GLU_BF16) {
         // interleaved weights: tiles j = 0, 2 hold values, j = 1, 3 their gates; N/2 output columns
@@ -229,7 +243,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(const uint16_t* __restri
                                                         const uint16_t* __restrict__ W,
                                                         const float* __restrict__ bias,
                                                         const float* resid, void* C, int64_t N,
-                                                        int64_t K, float alpha, int n_tiles, int w_packed) {
+                                                        int64_t K, float alpha, int n_tiles, int flags) {
+    const bool w_packed = flags & OASR_GEMM_W_PACKED, a_packed = flags & OASR_GEMM_A_PACKED, c_packed = flags & OASR_GEMM_C_PACKED;
     // ONE object on purpose: with the ring in an array of its own the compiler orders every fragment
     // read after all copies in flight (s_waitcnt vmcnt(0) per slice), which serialises the ring
     __shared__ __attribute__((aligned(1024))) char smem[2 * kRing * kSliceBytes + 8 * kEpiSlab + 8 * 2 * 256];  // A ring | W ring | slabs | bias strips
@@ -289,18 +304,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(const uint16_t* __restri
     const uint32_t lane_off_w = w_packed ? (uint32_t)lane * 16 : lane_off;
     const int64_t piece_stride_w = w_packed ? (int64_t)nph * 1024 : piece_stride;
     const int w_step = w_packed ? 1024 : BK * 2;
+    const uint32_t lane_off_a = a_packed ? (uint32_t)lane * 16 : lane_off;
+    const int64_t piece_stride_a = a_packed ? (int64_t)nph * 1024 : piece_stride;
+    const int a_step = a_packed ? 1024 : BK * 2;
     int st_i = 0, st_t = 0;
     const char *st_a, *st_w;
     auto stage_seek = [&](int i) {
         int64_t m0, n0;
         tile_origin(i, m0, n0);
-        st_a = reinterpret_cast<const char*>(A) + (m0 + wave * 32) * K * 2;
+        st_a = reinterpret_cast<const char*>(A) + (a_packed ? ((m0 + wave * 32) >> 4) * (int64_t)nph * 1024 : (m0 + wave * 32) * K * 2);
         st_w = reinterpret_cast<const char*>(W) + (w_packed ? ((n0 + wave * 32) >> 4) * (int64_t)nph * 1024 : (n0 + wave * 32) * K * 2);
     };
     auto stage_next = [&](int p) {  // global phase p = st_i * nph + st_t  ->  ring slot p & 3
-        stage_slice(st_a, lane_off, piece_stride, smem + (p & 3) * kSliceBytes, wave);
+        stage_slice(st_a, lane_off_a, piece_stride_a, smem + (p & 3) * kSliceBytes, wave);
         stage_slice(st_w, lane_off_w, piece_stride_w, smem + (kRing + (p & 3)) * kSliceBytes, wave);
-        st_a += BK * 2;
+        st_a += a_step;
         st_w += w_step;
         if (++st_t == nph) {
             st_t = 0;
@@ -387,7 +405,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(const uint16_t* __restri
             if (!(wm == 1 && t == nph - 1)) OASR_RAW_BARRIER();
         }
         gemm_epilogue<EPI>(acc, resid, C, N, alpha, m0 + wm * 128, n0 + wn * 64, lane,
-                           smem + 2 * kRing * kSliceBytes + wave * kEpiSlab);
+                           smem + 2 * kRing * kSliceBytes + wave * kEpiSlab, c_packed);
         if (wm == 1) OASR_RAW_BARRIER();
     }
     if (wm == 0) OASR_RAW_BARRIER();  // same barrier count in both groups
@@ -409,7 +427,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_small_kernel(const uint16_t*
                                                                  const uint16_t* __restrict__ W,
                                                                  const float* __restrict__ bias, const float* resid,
                                                                  void* C, int64_t N, int64_t K, float alpha,
-                                                                 int tiles_m, int n_tiles, int w_packed) {
+                                                                 int tiles_m, int n_tiles, int flags) {
+    const bool w_packed = flags & OASR_GEMM_W_PACKED, a_packed = flags & OASR_GEMM_A_PACKED, c_packed = flags & OASR_GEMM_C_PACKED;
     __shared__ __attribute__((aligned(1024))) char smem[2 * kRing * kSmallSlice + 4 * kEpiSlab];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -445,12 +464,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_small_kernel(const uint16_t*
     const uint32_t lane_off_w = w_packed ? (uint32_t)lane * 16 : lane_off;
     const int64_t piece_stride_w = w_packed ? (int64_t)nph * 1024 : piece_stride;
     const int w_step = w_packed ? 1024 : BK * 2;
-    const char* st_a = reinterpret_cast<const char*>(A) + (m0 + wave * 32) * K * 2;
+    const uint32_t lane_off_a = a_packed ? (uint32_t)lane * 16 : lane_off;
+    const int64_t piece_stride_a = a_packed ? (int64_t)nph * 1024 : piece_stride;
+    const int a_step = a_packed ? 1024 : BK * 2;
+    const char* st_a = reinterpret_cast<const char*>(A) + (a_packed ? ((m0 + wave * 32) >> 4) * (int64_t)nph * 1024 : (m0 + wave * 32) * K * 2);
     const char* st_w = reinterpret_cast<const char*>(W) + (w_packed ? ((n0 + wave * 32) >> 4) * (int64_t)nph * 1024 : (n0 + wave * 32) * K * 2);
     auto stage_next = [&](int p) {
-        stage_slice(st_a, lane_off, piece_stride, smem + (p & 3) * kSmallSlice, wave);
+        stage_slice(st_a, lane_off_a, piece_stride_a, smem + (p & 3) * kSmallSlice, wave);
         stage_slice(st_w, lane_off_w, piece_stride_w, smem + (kRing + (p & 3)) * kSmallSlice, wave);
-        st_a += BK * 2;
+        st_a += a_step;
         st_w += w_step;
     };
     stage_next(0);
@@ -485,7 +507,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_small_kernel(const uint16_t*
                 acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[ii], acc[ii][j], 0, 0, 0);
     }
     gemm_epilogue<EPI, 4>(acc, resid, C, N, alpha, m0 + wm * 64, n0 + wn * 64, lane,
-                          smem + 2 * kRing * kSmallSlice + wave * kEpiSlab);
+                          smem + 2 * kRing * kSmallSlice + wave * kEpiSlab, c_packed);
 }
 
 // Row-major bf16 weights [n][k] -> the packed form read by the kernels above: one thread per 16-byte chunk;
@@ -509,7 +531,7 @@ using namespace oasr;
 
 static int gemm_bf16_launch(const uint16_t* a, const uint16_t* w, const float* bias, const float* resid, void* c,
                             int64_t m, int64_t n, int64_t k, float alpha, int32_t epilogue, void* stream,
-                            int w_packed) {
+                            int flags) {
     OASR_REQUIRE(a && w && c, "gemm: null pointer");
     OASR_REQUIRE(m > 0 && n > 0 && k > 0 && m % BM == 0 && n % BN == 0 && k % BK == 0,
                  "gemm: m=%lld n=%lld must be multiples of 256 and k=%lld of 32", (long long)m,
@@ -519,13 +541,16 @@ static int gemm_bf16_launch(const uint16_t* a, const uint16_t* w, const float* b
                      ((uintptr_t)bias & 15) == 0 && ((uintptr_t)resid & 15) == 0,
                  "gemm: operands must be 16-byte aligned");
     OASR_REQUIRE(epilogue != OASR_EPI_RESIDUAL_F32 || resid != nullptr, "gemm: residual epilogue without resid");
+    OASR_REQUIRE((flags & ~(OASR_GEMM_W_PACKED | OASR_GEMM_A_PACKED | OASR_GEMM_C_PACKED)) == 0, "gemm: unknown flag bits %d", flags);
+    OASR_REQUIRE(!(flags & OASR_GEMM_C_PACKED) || epilogue == OASR_EPI_BIAS_BF16 || epilogue == OASR_EPI_BIAS_SWISH_BF16,
+                 "gemm: packed output exists for the two bf16 bias epilogues only");
     const int tiles = (int)((m / BM) * (n / BN));
     if (tiles < kMaxCUs / 2) {   // 256 x 256 tiles for fewer than half of the CUs: 128 x 128 tiles, same arithmetic
         // (measured: faster below ~128 large tiles, slower at 192)
         const int tm = (int)(m / kSmallTile), nt = tm * (int)(n / kSmallTile);
         hipStream_t st = (hipStream_t)stream;
 #define OASR_LAUNCH_SMALL(E) \
-    hipLaunchKernelGGL((gemm_bf16_small_kernel<E>), dim3((unsigned)nt), dim3(256), 0, st, a, w, bias, resid, c, n, k, alpha, tm, nt, w_packed)
+    hipLaunchKernelGGL((gemm_bf16_small_kernel<E>), dim3((unsigned)nt), dim3(256), 0, st, a, w, bias, resid, c, n, k, alpha, tm, nt, flags)
         switch (epilogue) {
             case OASR_EPI_BIAS_BF16: OASR_LAUNCH_SMALL(OASR_EPI_BIAS_BF16); break;
             case OASR_EPI_BIAS_SWISH_BF16: OASR_LAUNCH_SMALL(OASR_EPI_BIAS_SWISH_BF16); break;
@@ -547,9 +572,9 @@ static int gemm_bf16_launch(const uint16_t* a, const uint16_t* w, const float* b
 #define OASR_LAUNCH_GEMM(E)                                                                                          \
     do {                                                                                                             \
         if (k >= 2048)                                                                                               \
-            hipLaunchKernelGGL((gemm_bf16_kernel<E, true>), grid, blk, 0, st, a, w, bias, resid, c, n, k, alpha, tiles, w_packed);  \
+            hipLaunchKernelGGL((gemm_bf16_kernel<E, true>), grid, blk, 0, st, a, w, bias, resid, c, n, k, alpha, tiles, flags);  \
         else                                                                                                         \
-            hipLaunchKernelGGL((gemm_bf16_kernel<E, false>), grid, blk, 0, st, a, w, bias, resid, c, n, k, alpha, tiles, w_packed); \
+            hipLaunchKernelGGL((gemm_bf16_kernel<E, false>), grid, blk, 0, st, a, w, bias, resid, c, n, k, alpha, tiles, flags); \
     } while (0)
     switch (epilogue) {
         case OASR_EPI_BIAS_BF16: OASR_LAUNCH_GEMM(OASR_EPI_BIAS_BF16); break;
@@ -575,7 +600,13 @@ extern "C" int oasr_gemm_bf16(const uint16_t* a, const uint16_t* w, const float*
 extern "C" int oasr_gemm_bf16_pw(const uint16_t* a, const uint16_t* w_packed, const float* bias,
                                  const float* resid, void* c, int64_t m, int64_t n, int64_t k,
                                  float alpha, int32_t epilogue, void* stream) {
-    return gemm_bf16_launch(a, w_packed, bias, resid, c, m, n, k, alpha, epilogue, stream, 1);
+    return gemm_bf16_launch(a, w_packed, bias, resid, c, m, n, k, alpha, epilogue, stream, OASR_GEMM_W_PACKED);
+}
+
+extern "C" int oasr_gemm_bf16_ex(const uint16_t* a, const uint16_t* w, const float* bias, const float* resid, void* c,
+                                 int64_t m, int64_t n, int64_t k, float alpha, int32_t epilogue, int32_t flags,
+                                 void* stream) {
+    return gemm_bf16_launch(a, w, bias, resid, c, m, n, k, alpha, epilogue, stream, flags);
 }
 
 extern "C" int oasr_gemm_pack_w_bf16(const uint16_t* w, int64_t n, int64_t k, uint16_t* out, void* stream) {

@@ -19,6 +19,7 @@ _lib = None
 c_i32, c_i64, c_f32, c_f64, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
 
 EPI_BIAS_BF16, EPI_BIAS_SWISH_BF16, EPI_GLU_BF16, EPI_RESIDUAL_F32, EPI_BIAS_F32 = range(5)
+GEMM_W_PACKED, GEMM_A_PACKED, GEMM_C_PACKED = 1, 2, 4    # layout flags of oasr_gemm_bf16_ex
 
 
 class EncoderConfig(C.Structure):
@@ -88,6 +89,7 @@ _SIGNATURES = {
     "oasr_gemm_bf16": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_i32, c_vp]),
     "oasr_gemm_bf16_pw": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_i32, c_vp]),
     "oasr_gemm_pack_w_bf16": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp]),
+    "oasr_gemm_bf16_ex": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_i32, c_i32, c_vp]),
     "oasr_encoder_set_packed_weights": (c_i32, [c_vp, c_i32]),
     "oasr_encoder_set_fp8": (c_i32, [c_vp, c_vp]),
     "oasr_layernorm_fp8": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_i32, c_vp]),

@@ -9,7 +9,6 @@ not re-entrant: callers serialise `encode_batch` (the pipeline holds a lock).
 from __future__ import annotations
 
 import ctypes as C
-import os
 
 import numpy as np
 import torch
@@ -40,9 +39,7 @@ class HipEngine:
             weights = init_random_weights(g, seed)
         self.fp8 = bool(fp8)    # e4m3 weights + per-row quantised activations in the eight large projections
         self._packed = pack_for_device(weights, g, self.device, fp8=self.fp8)   # keeps device buffers alive
-        self._packed["gemm_weights_packed"] = False
-        if not os.environ.get("OASR_ROWMAJOR_WEIGHTS"):   # A/B switch: keep the projection matrices row-major
-            self._pack_gemm_weights()
+        self._pack_gemm_weights()
         self._tables = torch.from_numpy(_hip.logmel_table_blob().view(np.int32)).to(self.device)
         self._handle = self._create_handle()
         self._buffers: dict = {}

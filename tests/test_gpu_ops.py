@@ -484,3 +484,40 @@ def test_gemm_packed_weights_equal_row_major_bit_for_bit(m, n, k, epi):
     assert torch.equal(outs[0], outs[1])
     assert H.lib().oasr_gemm_pack_w_bf16(wd.data_ptr(), n, k, wd.data_ptr(), _stream()) != 0      # in place: refused
     assert H.lib().oasr_gemm_pack_w_bf16(wd.data_ptr(), n + 8, k, wp.data_ptr(), _stream()) != 0   # n not a multiple of 16
+
+
+@pytest.mark.parametrize("m,n,k,epi", [(4352, 4096, 1024, 1), (768, 512, 64, 0), (2304, 2048, 96, 1)])
+def test_gemm_packed_output_then_packed_input(m, n, k, epi):
+    """OASR_GEMM_C_PACKED writes the bf16 product in the packed layout (equal to packing the row-major
+    product), and a second product taking it as packed A equals the one on the row-major matrix."""
+    H = _lib()
+    L = H.lib()
+    g = torch.Generator().manual_seed(m * 3 + n + k)
+    a = _bf(torch.randn((m, k), generator=g)).cuda()
+    w = _bf(torch.randn((n, k), generator=g) / math.sqrt(k)).cuda()
+    bias = torch.randn((n,), generator=g).cuda()
+    c_row = torch.zeros((m, n), dtype=torch.bfloat16, device="cuda")
+    c_pk = torch.zeros_like(c_row)
+    H.check(L.oasr_gemm_bf16_ex(a.data_ptr(), w.data_ptr(), bias.data_ptr(), None, c_row.data_ptr(), m, n, k, 1.0, epi, 0, _stream()))
+    H.check(L.oasr_gemm_bf16_ex(a.data_ptr(), w.data_ptr(), bias.data_ptr(), None, c_pk.data_ptr(), m, n, k, 1.0, epi,
+                                H.GEMM_C_PACKED, _stream()))
+    want = torch.empty_like(c_row)
+    H.check(L.oasr_gemm_pack_w_bf16(c_row.data_ptr(), m, n, want.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(c_pk, want)
+    # second product: [m][n] x [n2][n]^T with the float32 residual epilogue, A row-major against A packed
+    n2 = 512
+    w2 = _bf(torch.randn((n2, n), generator=g) / math.sqrt(n)).cuda()
+    b2 = torch.randn((n2,), generator=g).cuda()
+    resid = torch.randn((m, n2), generator=g).cuda()
+    outs = []
+    for amat, flags in ((c_row, 0), (c_pk, H.GEMM_A_PACKED)):
+        c2 = torch.zeros((m, n2), dtype=torch.float32, device="cuda")
+        H.check(L.oasr_gemm_bf16_ex(amat.data_ptr(), w2.data_ptr(), b2.data_ptr(), resid.data_ptr(), c2.data_ptr(), m, n2, n,
+                                    0.5, H.EPI_RESIDUAL_F32, flags, _stream()))
+        outs.append(c2)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    assert L.oasr_gemm_bf16_ex(a.data_ptr(), w.data_ptr(), bias.data_ptr(), None, c_pk.data_ptr(), m, n, k, 1.0,
+                               H.EPI_BIAS_F32, H.GEMM_C_PACKED, _stream()) != 0   # float32 outputs have no packed form
+    assert L.oasr_gemm_bf16_ex(a.data_ptr(), w.data_ptr(), bias.data_ptr(), None, c_pk.data_ptr(), m, n, k, 1.0, epi, 8, _stream()) != 0
