@@ -128,8 +128,9 @@ def kernel_rooflines(engine, batch: int, t_pad: int, pcm, nv, hidden) -> dict:
     def gemm(a, wname, bias, res, c, n, k, alpha, epi, quant=True):
         def run():
             if fp8:
-                _hip.check(L.oasr_gemm_fp8(a8.data_ptr(), lw[wname + "_q"].data_ptr(), sa.data_ptr(),
-                                           lw[wname + "_s"].data_ptr(), bias, res, c.data_ptr(), rows, n, k, alpha, epi, st))
+                fn8 = L.oasr_gemm_fp8_pw if engine._packed["gemm_weights_packed"] else L.oasr_gemm_fp8
+                _hip.check(fn8(a8.data_ptr(), lw[wname + "_q"].data_ptr(), sa.data_ptr(),
+                               lw[wname + "_s"].data_ptr(), bias, res, c.data_ptr(), rows, n, k, alpha, epi, st))
             else:
                 fn = L.oasr_gemm_bf16_pw if engine._packed["gemm_weights_packed"] else L.oasr_gemm_bf16
                 _hip.check(fn(a.data_ptr(), lw[wname].data_ptr(), bias, res, c.data_ptr(), rows, n, k, alpha, epi, st))

@@ -183,7 +183,8 @@ typedef struct oasr_layer_fp8_weights {
 int oasr_encoder_set_fp8(oasr_encoder* enc, const oasr_layer_fp8_weights* layers);
 /* Declares that every bf16 projection matrix handed to oasr_encoder_create (fp_w and the eight per layer:
  * ffn1_w1, ffn1_w2, wqkv, wo, pw1, pw2, ffn2_w1, ffn2_w2) is in the packed layout of oasr_gemm_pack_w_bf16
- * (packed != 0) or row-major (0, the default).  Same results either way; packed copies faster. */
+ * (packed != 0) or row-major (0, the default); with fp8 weights set, the same holds for their e4m3 matrices
+ * (oasr_gemm_pack_w_fp8).  Same results either way; packed copies faster. */
 int oasr_encoder_set_packed_weights(oasr_encoder* enc, int32_t packed);
 
 /* Rows of the activation matrices for a batch: round_up(batch * t_pad, 256). */
@@ -282,6 +283,12 @@ int oasr_quant_fp8_rows(const uint16_t* x, int64_t rows, int64_t k, uint8_t* y, 
 int oasr_gemm_fp8(const uint8_t* a, const uint8_t* w, const float* scale_a, const float* scale_w,
                   const float* bias, const float* resid, void* c, int64_t m, int64_t n, int64_t k,
                   float alpha, int32_t epilogue, void* stream);
+/* The fp8 product with W in the packed layout (as oasr_gemm_bf16_pw): 1 KiB pieces of 16 rows x 64 k made by
+ * oasr_gemm_pack_w_fp8 (n a multiple of 16, k of 64; out must not alias w).  Bit-identical results. */
+int oasr_gemm_pack_w_fp8(const uint8_t* w, int64_t n, int64_t k, uint8_t* out, void* stream);
+int oasr_gemm_fp8_pw(const uint8_t* a, const uint8_t* w_packed, const float* scale_a, const float* scale_w,
+                     const float* bias, const float* resid, void* c, int64_t m, int64_t n, int64_t k,
+                     float alpha, int32_t epilogue, void* stream);
 
 /* Multi-head self-attention with clamped relative-key bias and key-length masking.
  * qkv bf16 [rows][3*d] (q | k | v), ctx bf16 [rows][d], d = n_heads * head_dim; head_dim 64

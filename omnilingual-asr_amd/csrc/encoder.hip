@@ -160,7 +160,7 @@ int oasr_encoder_forward(const oasr_encoder* enc, const float* feats, const int3
                        int layout = 0) -> int {
         if (!fp8) return oasr_gemm_bf16_ex(a, wb, bias, resid, dst, rows, n, k, alpha, epi, wflag | layout, stream);
         if (a) OASR_TRY(oasr_quant_fp8_rows(a, rows, k, ws.a8, ws.sa, stream));
-        return oasr_gemm_fp8(ws.a8, wq, ws.sa, wscale, bias, resid, dst, rows, n, k, alpha, epi, stream);
+        return (enc->packed_w ? oasr_gemm_fp8_pw : oasr_gemm_fp8)(ws.a8, wq, ws.sa, wscale, bias, resid, dst, rows, n, k, alpha, epi, stream);
     };
     // LayerNorm feeding a projection: bf16 rows in ws.xn, or (fp8 path) e4m3 rows + scales in ws.a8 / ws.sa
     auto norm = [&](const float* src, const float* lw, const float* lb, int64_t nrows, int swish) -> int {

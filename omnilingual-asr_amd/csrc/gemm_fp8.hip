@@ -173,7 +173,7 @@ __global__ __launch_bounds__(512) void gemm_fp8_kernel(const uint8_t* __restrict
                                                        const float* __restrict__ scale_a,
                                                        const float* __restrict__ scale_w,
                                                        const float* __restrict__ bias, const float* resid, void* C,
-                                                       int64_t N, int64_t K, float alpha, int n_tiles) {
+                                                       int64_t N, int64_t K, float alpha, int n_tiles, int w_packed) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * kRing * kSliceBytes + 8 * kEpiSlab];  // A ring | W ring | slabs
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -228,19 +228,23 @@ __global__ __launch_bounds__(512) void gemm_fp8_kernel(const uint8_t* __restrict
     // Staging cursor (see gemm_bf16.hip): bytes instead of bf16 pairs.
     const uint32_t lane_off = (uint32_t)((lane >> 2) * K + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));
     const int64_t piece_stride = 16 * K;
+    // packed weights (oasr_gemm_pack_w_fp8): piece (row group g, slice t) lies at (g * nph + t) KiB, lanes in order
+    const uint32_t lane_off_w = w_packed ? (uint32_t)lane * 16 : lane_off;
+    const int64_t piece_stride_w = w_packed ? (int64_t)nph * 1024 : piece_stride;
+    const int w_step = w_packed ? 1024 : BK;
     int st_i = 0, st_t = 0;
     const char *st_a, *st_w;
     auto stage_seek = [&](int i) {
         int64_t m0, n0;
         tile_origin(i, m0, n0);
         st_a = reinterpret_cast<const char*>(A) + (m0 + wave * 32) * K;
-        st_w = reinterpret_cast<const char*>(W) + (n0 + wave * 32) * K;
+        st_w = reinterpret_cast<const char*>(W) + (w_packed ? ((n0 + wave * 32) >> 4) * (int64_t)nph * 1024 : (n0 + wave * 32) * K);
     };
     auto stage_next = [&](int p) {
         stage_slice(st_a, lane_off, piece_stride, smem + (p & 3) * kSliceBytes, wave);
-        stage_slice(st_w, lane_off, piece_stride, smem + (kRing + (p & 3)) * kSliceBytes, wave);
+        stage_slice(st_w, lane_off_w, piece_stride_w, smem + (kRing + (p & 3)) * kSliceBytes, wave);
         st_a += BK;
-        st_w += BK;
+        st_w += w_step;
         if (++st_t == nph) {
             st_t = 0;
             if (++st_i < my_tiles) stage_seek(st_i);
@@ -390,6 +394,22 @@ __global__ __launch_bounds__(256) void quant_fp8_rows_reg_kernel(const uint16_t*
     }
 }
 
+
+// Row-major e4m3 weights [n][k] -> the packed form: 1 KiB pieces of 16 rows x 64 k in the byte order a copy
+// instruction places them (chunk `lane` = row lane >> 2, source chunk (lane & 3) ^ ((row >> 2) & 3)), pieces
+// ordered [row group][K slice].
+__global__ __launch_bounds__(256) void gemm_pack_w8_kernel(const uint8_t* __restrict__ w, uint8_t* __restrict__ out,
+                                                           int64_t n, int64_t k) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;   // 16-byte chunk of the output
+    const int64_t nph = k / BK, total = (n / 16) * nph * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const int64_t piece = idx >> 6, g = piece / nph, t = piece - g * nph;
+    const int row = lane >> 2, chunk = (lane & 3) ^ ((lane >> 4) & 3);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(w + (g * 16 + row) * k + t * BK + chunk * 16);
+    *reinterpret_cast<u32x4*>(out + idx * 16) = v;
+}
+
 }  // namespace f8
 }  // namespace oasr
 
@@ -416,9 +436,9 @@ extern "C" int oasr_quant_fp8_rows(const uint16_t* x, int64_t rows, int64_t k, u
     return OASR_OK;
 }
 
-extern "C" int oasr_gemm_fp8(const uint8_t* a, const uint8_t* w, const float* scale_a, const float* scale_w,
-                             const float* bias, const float* resid, void* c, int64_t m, int64_t n, int64_t k,
-                             float alpha, int32_t epilogue, void* stream) {
+static int gemm_fp8_launch(const uint8_t* a, const uint8_t* w, const float* scale_a, const float* scale_w,
+                           const float* bias, const float* resid, void* c, int64_t m, int64_t n, int64_t k,
+                           float alpha, int32_t epilogue, void* stream, int w_packed) {
     OASR_REQUIRE(a && w && scale_a && scale_w && c, "gemm_fp8: null pointer");
     OASR_REQUIRE(m > 0 && n > 0 && k > 0 && m % f8::BM == 0 && n % f8::BN == 0 && k % f8::BK == 0,
                  "gemm_fp8: m=%lld n=%lld must be multiples of 256 and k=%lld of 64", (long long)m, (long long)n,
@@ -433,7 +453,7 @@ extern "C" int oasr_gemm_fp8(const uint8_t* a, const uint8_t* w, const float* sc
     hipStream_t st = (hipStream_t)stream;
 #define OASR_LAUNCH_GEMM8(E)                                                                                    \
     hipLaunchKernelGGL((f8::gemm_fp8_kernel<E>), grid, blk, 0, st, a, w, scale_a, scale_w, bias, resid, c, n, k, \
-                       alpha, tiles)
+                       alpha, tiles, w_packed)
     switch (epilogue) {
         case OASR_EPI_BIAS_BF16: OASR_LAUNCH_GEMM8(OASR_EPI_BIAS_BF16); break;
         case OASR_EPI_BIAS_SWISH_BF16: OASR_LAUNCH_GEMM8(OASR_EPI_BIAS_SWISH_BF16); break;
@@ -446,5 +466,29 @@ extern "C" int oasr_gemm_fp8(const uint8_t* a, const uint8_t* w, const float* sc
     }
 #undef OASR_LAUNCH_GEMM8
     OASR_CHECK_LAUNCH("gemm_fp8");
+    return OASR_OK;
+}
+
+extern "C" int oasr_gemm_fp8(const uint8_t* a, const uint8_t* w, const float* scale_a, const float* scale_w,
+                             const float* bias, const float* resid, void* c, int64_t m, int64_t n, int64_t k,
+                             float alpha, int32_t epilogue, void* stream) {
+    return gemm_fp8_launch(a, w, scale_a, scale_w, bias, resid, c, m, n, k, alpha, epilogue, stream, 0);
+}
+
+extern "C" int oasr_gemm_fp8_pw(const uint8_t* a, const uint8_t* w_packed, const float* scale_a, const float* scale_w,
+                                const float* bias, const float* resid, void* c, int64_t m, int64_t n, int64_t k,
+                                float alpha, int32_t epilogue, void* stream) {
+    return gemm_fp8_launch(a, w_packed, scale_a, scale_w, bias, resid, c, m, n, k, alpha, epilogue, stream, 1);
+}
+
+extern "C" int oasr_gemm_pack_w_fp8(const uint8_t* w, int64_t n, int64_t k, uint8_t* out, void* stream) {
+    OASR_REQUIRE(w && out && w != out, "gemm_pack_w_fp8: null pointer or in-place call");
+    OASR_REQUIRE(n > 0 && k > 0 && n % 16 == 0 && k % f8::BK == 0, "gemm_pack_w_fp8: n=%lld must be a multiple of 16 and k=%lld of 64",
+                 (long long)n, (long long)k);
+    OASR_REQUIRE(((uintptr_t)w & 15) == 0 && ((uintptr_t)out & 15) == 0, "gemm_pack_w_fp8: operands must be 16-byte aligned");
+    const int64_t chunks = n * k / 16;
+    OASR_REQUIRE(chunks / 256 + 1 < ((int64_t)1 << 31), "gemm_pack_w_fp8: matrix too large");
+    hipLaunchKernelGGL(f8::gemm_pack_w8_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, out, n, k);
+    OASR_CHECK_LAUNCH("gemm_pack_w_fp8");
     return OASR_OK;
 }

@@ -96,6 +96,8 @@ _SIGNATURES = {
     "oasr_layernorm2_fp8": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_f32, c_vp]),
     "oasr_quant_fp8_rows": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "oasr_gemm_fp8": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_i32, c_vp]),
+    "oasr_gemm_fp8_pw": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_i32, c_vp]),
+    "oasr_gemm_pack_w_fp8": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp]),
     "oasr_attention_relkey": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "oasr_dwconv_causal": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp]),
     "oasr_dwconv_ln_swish": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_f32, c_vp]),

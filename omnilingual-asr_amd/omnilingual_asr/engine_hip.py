@@ -67,10 +67,18 @@ class HipEngine:
                            "oasr_gemm_pack_w_bf16")
                 return out
 
+            def packed8(w):
+                out = torch.empty_like(w)
+                _hip.check(L.oasr_gemm_pack_w_fp8(w.data_ptr(), w.shape[0], w.shape[1], out.data_ptr(), st),
+                           "oasr_gemm_pack_w_fp8")
+                return out
+
             self._packed["top"]["fp_w"] = packed(self._packed["top"]["fp_w"])
             for layer in self._packed["layers"]:
                 for name in self.GEMM_WEIGHTS:
                     layer[name] = packed(layer[name])
+                    if self.fp8:
+                        layer[name + "_q"] = packed8(layer[name + "_q"])
             if "ctc_w" in self._packed:
                 self._packed["ctc_w"] = packed(self._packed["ctc_w"])
             torch.cuda.synchronize()

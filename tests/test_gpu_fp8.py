@@ -213,3 +213,35 @@ def test_encoder_block_at_the_7b_width_bf16_and_fp8():
         assert rel(h8[i, :n], ref8[i, :n]) <= 3e-2
         assert rel(h8[i, :n], ref16[i, :n]) <= 1.5e-1
         assert rel(h8[i, :n], h16[i, :n]) > 5e-3
+
+
+@pytest.mark.parametrize("m,n,k,epi", [(2304, 4096, 1024, 1), (512, 512, 128, 3), (4352, 1024, 4096, 3)])
+def test_fp8_gemm_packed_weights_equal_row_major_bit_for_bit(m, n, k, epi):
+    """oasr_gemm_pack_w_fp8 against a restatement with tensor operations, and oasr_gemm_fp8_pw on the packed
+    matrix against oasr_gemm_fp8 on the row-major one."""
+    from omnilingual_asr import _hip as H
+    L = H.lib()
+    st = H.current_stream_ptr()
+    g = torch.Generator().manual_seed(m + n + k)
+    a8 = torch.randint(0, 120, (m, k), generator=g, dtype=torch.uint8).cuda()      # positive finite e4m3 codes
+    w8 = torch.randint(0, 120, (n, k), generator=g, dtype=torch.uint8)
+    w8d = w8.cuda()
+    wp = torch.empty_like(w8d)
+    H.check(L.oasr_gemm_pack_w_fp8(w8d.data_ptr(), n, k, wp.data_ptr(), st))
+    v = w8.view(n // 16, 16, k // 64, 4, 16).permute(0, 2, 1, 3, 4)                 # [group][slice][row][chunk][16]
+    rows = torch.arange(16).view(16, 1)
+    src = torch.arange(4).view(1, 4) ^ ((rows >> 2) & 3)
+    torch.cuda.synchronize()
+    assert torch.equal(wp.cpu(), v[:, :, rows, src].reshape(n, k))
+    sa = (torch.rand((m,), generator=g) + 0.5).cuda()
+    sw = (torch.rand((n,), generator=g) + 0.5).cuda()
+    bias = torch.randn((n,), generator=g).cuda()
+    resid = torch.randn((m, n), generator=g).cuda() if epi == 3 else None
+    outs = []
+    for fn, wmat in ((L.oasr_gemm_fp8, w8d), (L.oasr_gemm_fp8_pw, wp)):
+        c = torch.zeros((m, n), dtype=torch.float32 if epi == 3 else torch.bfloat16, device="cuda")
+        H.check(fn(a8.data_ptr(), wmat.data_ptr(), sa.data_ptr(), sw.data_ptr(), bias.data_ptr(),
+                   None if resid is None else resid.data_ptr(), c.data_ptr(), m, n, k, 0.5, epi, st))
+        outs.append(c)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
