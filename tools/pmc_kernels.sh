@@ -23,8 +23,9 @@ run() {  # name, program args...
             || { echo "pass $i of $name failed"; tail -3 "$OUT/${name}_p$i.log"; exit 1; }
     done
 }
-run ffn_up   python3 "$R/tools/gemm_one.py" 48128 4096 1024 1
-run ffn_down python3 "$R/tools/gemm_one.py" 48128 1024 4096 3
-run dxd_res  python3 "$R/tools/gemm_one.py" 48128 1024 1024 3
+# layout flags as in the encoder: weights packed everywhere; up-projection output and down-projection input packed too
+run ffn_up   python3 "$R/tools/gemm_one.py" 48128 4096 1024 1 5
+run ffn_down python3 "$R/tools/gemm_one.py" 48128 1024 4096 3 3
+run dxd_res  python3 "$R/tools/gemm_one.py" 48128 1024 1024 3 1
 run attn64   python3 "$R/tools/attn_one.py" 3
 python3 "$R/tools/pmc_table.py" "$OUT"

@@ -15,7 +15,7 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
     python3 "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-graph > "$OUT/${TAG}_stats_eager.log" 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
     timeout -s KILL 120 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/${TAG}_pmc_gemm_$C" -- \
-        python3 "$R/tools/gemm_one.py" > "$OUT/${TAG}_pmc_gemm_$C.log" 2>&1
+        python3 "$R/tools/gemm_one.py" 48128 4096 1024 1 5 > "$OUT/${TAG}_pmc_gemm_$C.log" 2>&1
     timeout -s KILL 120 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/${TAG}_pmc_logmel_$C" -- \
         python3 "$R/tools/logmel_one.py" 5 > "$OUT/${TAG}_pmc_logmel_$C.log" 2>&1
 done
