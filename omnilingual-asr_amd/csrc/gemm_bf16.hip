@@ -136,7 +136,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][4],
             for (int j = 0; j < 4; ++j) {
                 f32x4 v = acc[i][j];
                 if (EPI == OASR_EPI_BIAS_SWISH_BF16) {
-                    v[0] = swishf(v[0]); v[1] = swishf(v[1]); v[2] = swishf(v[2]); v[3] = swishf(v[3]);
+                    const f32x2 lo = swish2((f32x2){v[0], v[1]}), hi = swish2((f32x2){v[2], v[3]});
+                    v = (f32x4){lo[0], lo[1], hi[0], hi[1]};
                 }
                 *reinterpret_cast<uint2*>(slab + fr * kEpiPitch + j * 32 + fq * 8) =
                     make_uint2(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]));
@@ -166,9 +167,10 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MI][4],
 #pragma unroll
             for (int j = 0; j < 4; j += 2) {
                 const f32x4 v = acc[i][j], g = acc[i][j + 1];
+                const f32x2 lo = (f32x2){v[0], v[1]} * sigmoid2((f32x2){g[0], g[1]});
+                const f32x2 hi = (f32x2){v[2], v[3]} * sigmoid2((f32x2){g[2], g[3]});
                 *reinterpret_cast<uint2*>(slab + fr * kEpiPitch + (j >> 1) * 32 + fq * 8) =
-                    make_uint2(cvt_pk_bf16(v[0] * sigmoidf(g[0]), v[1] * sigmoidf(g[1])),
-                               cvt_pk_bf16(v[2] * sigmoidf(g[2]), v[3] * sigmoidf(g[3])));
+                    make_uint2(cvt_pk_bf16(lo[0], lo[1]), cvt_pk_bf16(hi[0], hi[1]));
             }
             OASR_WAVE_LDS_SYNC();
             const u32x4 o = *reinterpret_cast<const u32x4*>(slab + rrow * kEpiPitch + rchunk * 16);

@@ -144,7 +144,10 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[4][2], const float (&sam)
                     float4 o = make_float4(fmaf(v[r2].x, sw[h].x, bv[h].x), fmaf(v[r2].y, sw[h].y, bv[h].y),
                                            fmaf(v[r2].z, sw[h].z, bv[h].z), fmaf(v[r2].w, sw[h].w, bv[h].w));
                     if (EPI == OASR_EPI_BIAS_BF16 || EPI == OASR_EPI_BIAS_SWISH_BF16) {
-                        if (EPI == OASR_EPI_BIAS_SWISH_BF16) o = make_float4(swishf(o.x), swishf(o.y), swishf(o.z), swishf(o.w));
+                        if (EPI == OASR_EPI_BIAS_SWISH_BF16) {
+                            const f32x2 lo = swish2((f32x2){o.x, o.y}), hi = swish2((f32x2){o.z, o.w});
+                            o = make_float4(lo[0], lo[1], hi[0], hi[1]);
+                        }
                         const u32x2 pk = {cvt_pk_bf16(o.x, o.y), cvt_pk_bf16(o.z, o.w)};
                         __builtin_nontemporal_store(pk, reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(C) + index_of(i, h, r2)));
                     } else {

@@ -60,6 +60,15 @@ __device__ __forceinline__ float wave_max(float v) {
 // v_exp_f32 + v_rcp_f32 (1 ulp each): far inside the bf16 tolerance of every consumer
 __device__ __forceinline__ float sigmoidf(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float swishf(float x) { return x * sigmoidf(x); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Sigmoid / Swish of two values with the multiplies and the add as packed f32 instructions (v_pk_mul_f32,
+// v_pk_add_f32: two elements per issue slot); the same operations per element as sigmoidf / swishf, bit for bit.
+__device__ __forceinline__ f32x2 sigmoid2(f32x2 x) {
+    const f32x2 t = x * (f32x2){-1.442695040888963f, -1.442695040888963f};
+    const f32x2 d = (f32x2){__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + (f32x2){1.0f, 1.0f};
+    return (f32x2){__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
+__device__ __forceinline__ f32x2 swish2(f32x2 x) { return x * sigmoid2(x); }
 
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
