@@ -1,10 +1,14 @@
 #!/bin/bash
 # SQ / GRBM counter passes over the kernels that dominate the step: the three GEMM shapes of a block
 # and the attention kernel.  One rocprofv3 run per pass and target, counters only (no tracing domains
-# besides the kernel trace).  Usage on the GPU box: bash tools/pmc_kernels.sh <tag>
+# besides the kernel trace).  Usage on the GPU box: bash tools/pmc_kernels.sh <tag> [target ...]
+# (targets: ffn_up ffn_down dxd_res attn64 dwconv; default the first four)
 #   -> gpurun_out/<tag>_pmc/<target>_p<i>/...  and a table on stdout (tools/pmc_table.py)
 set -e
 TAG=${1:-r02}
+shift || true
+TARGETS=${*:-ffn_up ffn_down dxd_res attn64}
+want() { case " $TARGETS " in *" $1 "*) return 0;; esac; return 1; }
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/${TAG}_pmc
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -24,8 +28,9 @@ run() {  # name, program args...
     done
 }
 # layout flags as in the encoder: weights packed everywhere; up-projection output and down-projection input packed too
-run ffn_up   python3 "$R/tools/gemm_one.py" 48128 4096 1024 1 5
-run ffn_down python3 "$R/tools/gemm_one.py" 48128 1024 4096 3 3
-run dxd_res  python3 "$R/tools/gemm_one.py" 48128 1024 1024 3 1
-run attn64   python3 "$R/tools/attn_one.py" 3
+want ffn_up && run ffn_up   python3 "$R/tools/gemm_one.py" 48128 4096 1024 1 5
+want ffn_down && run ffn_down python3 "$R/tools/gemm_one.py" 48128 1024 4096 3 3
+want dxd_res && run dxd_res  python3 "$R/tools/gemm_one.py" 48128 1024 1024 3 1
+want attn64 && run attn64   python3 "$R/tools/attn_one.py" 3
+want dwconv && run dwconv python3 "$R/tools/dwconv_one.py"
 python3 "$R/tools/pmc_table.py" "$OUT"

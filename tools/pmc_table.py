@@ -8,7 +8,8 @@ import os
 import sys
 
 root = sys.argv[1]
-targets = {"ffn_up": "gemm_bf16_kernel<1", "ffn_down": "gemm_bf16_kernel<3", "dxd_res": "gemm_bf16_kernel<3", "attn64": "attention"}
+targets = {"ffn_up": "gemm_bf16_kernel<1", "ffn_down": "gemm_bf16_kernel<3", "dxd_res": "gemm_bf16_kernel<3", "attn64": "attention",
+           "dwconv": "dwconv_ln_swish"}
 table = collections.OrderedDict()
 for name, needle in targets.items():
     acc = collections.defaultdict(list)
@@ -21,7 +22,8 @@ for name, needle in targets.items():
         for r in csv.DictReader(open(f)):
             if needle in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    table[name] = {k: sorted(v)[len(v) // 2] for k, v in acc.items()}
+    if acc:
+        table[name] = {k: sorted(v)[len(v) // 2] for k, v in acc.items()}
 names = sorted({k for t in table.values() for k in t})
 md = "--md" in sys.argv
 sep = " | " if md else "  "
