@@ -71,11 +71,8 @@ __global__ __launch_bounds__(256) void dwconv_causal_kernel(const uint16_t* __re
 // Work items are (utterance, time tile) pairs; work-groups with equal blockIdx % 8 share an XCD
 // (observed round-robin placement; locality only), so each XCD gets a contiguous run of items and
 // the K - 1 input rows two neighbouring tiles share are served by one L2.
-#ifndef OASR_DW_ATTR
-#define OASR_DW_ATTR
-#endif
 template <int K, int VPL>
-__global__ __launch_bounds__(128 * VPL) OASR_DW_ATTR void dwconv_ln_swish_kernel(
+__global__ __launch_bounds__(128 * VPL) void dwconv_ln_swish_kernel(
     const uint16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ ln_w,
     const float* __restrict__ ln_b, uint16_t* __restrict__ y, int t_tiles, int64_t t_pad, float eps) {
     constexpr int D = 256 * VPL, kRows = kTimeTile + K - 1, kWaves = 2 * VPL;
