@@ -79,6 +79,38 @@ def read_wav(path) -> tuple[np.ndarray, int]:
     return x.reshape(n, channels), int(rate)
 
 
+def read_wav_pcm16_mono(path):
+    """(int16 [frames] view of the memory-mapped file, sample_rate) when `path` is a mono 16-bit PCM WAV, else
+    None.  The sample value in [-1, 1) is the integer / 32768; nothing is read, converted or copied here: the
+    pages are touched when chunks are copied into batches."""
+    import mmap
+    with open(path, "rb") as f:
+        size = f.seek(0, 2)
+        if size < 44:
+            return None
+        mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+    if mm[:4] != b"RIFF" or mm[8:12] != b"WAVE":
+        return None
+    fmt = data_at = data_len = None
+    pos = 12
+    while pos + 8 <= size:
+        cid = mm[pos:pos + 4]
+        n = struct.unpack_from("<I", mm, pos + 4)[0]
+        if cid == b"fmt ":
+            fmt = mm[pos + 8: pos + 8 + min(n, 40)]
+        elif cid == b"data":
+            data_at, data_len = pos + 8, min(n, size - pos - 8)
+        pos += 8 + n + (n & 1)
+    if fmt is None or data_at is None or len(fmt) < 16:
+        return None
+    tag, channels, rate, _, block, bits = struct.unpack_from("<HHIIHH", fmt, 0)
+    if tag == 0xFFFE and len(fmt) >= 26:
+        tag = struct.unpack_from("<H", fmt, 24)[0]
+    if tag != 1 or channels != 1 or bits != 16 or block != 2:
+        return None
+    return np.frombuffer(mm, dtype="<i2", count=data_len // 2, offset=data_at), int(rate)
+
+
 def wav_duration(path) -> float:
     """Duration in seconds from the header alone; raises on anything unreadable."""
     with open(path, "rb") as f:
@@ -277,9 +309,18 @@ def read_audio(path) -> tuple[np.ndarray, int]:
         f"cannot decode '{Path(path).suffix}' audio: WAV, AIFF and FLAC input is supported")
 
 
-def load_audio_16k(path, resampler=None) -> np.ndarray:
+def load_audio_16k(path, resampler=None, keep_int16: bool = False) -> np.ndarray:
     """File -> mono float32 at 16 kHz (channels averaged).  `resampler(mono, rate) -> float32 array`
-    replaces the host polyphase filter when given (the device engine passes its own)."""
+    replaces the host polyphase filter when given (the device engine passes its own).
+    With `keep_int16`, a mono 16-bit PCM WAV that is already at 16 kHz comes back as the int16 samples
+    themselves (value = integer / 32768, exactly what the float path computes): the caller converts while
+    it copies chunks into batches, so a long file is neither converted nor copied as a whole."""
+    if keep_int16:
+        with open(path, "rb") as f:
+            is_riff = f.read(4) == b"RIFF"
+        fast = read_wav_pcm16_mono(path) if is_riff else None
+        if fast is not None and fast[1] == TARGET_RATE:
+            return fast[0]
     x, rate = read_audio(path)
     mono = x.mean(axis=1, dtype=np.float64) if x.shape[1] > 1 else x[:, 0]
     if resampler is not None and rate != TARGET_RATE:

@@ -348,7 +348,10 @@ class GeminiASRPipeline:
                 else:
                     ticket, batch = None, np.empty((len(part), width), dtype=np.float32)
                 for i, (s, e) in enumerate(part):
-                    batch[i, : e - s] = pcm[s:e]
+                    if pcm.dtype == np.int16:      # 16-bit samples kept as read: scaled while copied
+                        np.multiply(pcm[s:e], np.float32(1.0 / 32768.0), out=batch[i, : e - s])
+                    else:
+                        batch[i, : e - s] = pcm[s:e]
                     batch[i, e - s:] = 0.0
                 job = None
                 try:
@@ -373,13 +376,14 @@ class GeminiASRPipeline:
         return records
 
     def _load_audio(self, audio_path) -> np.ndarray:
-        """Mono float32 at 16 kHz; the rate conversion runs on the device when the engine offers it."""
+        """Mono float32 at 16 kHz (int16 samples, value / 32768, for a mono 16-bit WAV already at 16 kHz: see
+        `load_audio_16k`); the rate conversion runs on the device when the engine offers it."""
         resampler = None
         if hasattr(self.engine, "resample_16k"):
             def resampler(mono, rate):
                 with self._engine_lock:
                     return self.engine.resample_16k(mono, rate).cpu().numpy()
-        return _audio.load_audio_16k(Path(audio_path), resampler)
+        return _audio.load_audio_16k(Path(audio_path), resampler, keep_int16=True)
 
     def _encode_file(self, pcm: np.ndarray, word_timestamps: bool) -> GeminiTranscriptionResult:
         """Plan on the decoded sample count, encode (this rank's shard when a process group is set),

@@ -68,3 +68,46 @@ def test_resampler_matches_scipy(rate):
 def test_gettysburg_fixture(golden_dir):
     x = audio.load_audio_16k(golden_dir / "gettysburg.wav")
     assert x.shape == (281233,) and x.dtype == np.float32 and np.abs(x).max() <= 1.0
+
+
+def test_int16_fast_path_equals_the_float_path(tmp_path):
+    """A mono 16-bit WAV at 16 kHz may come back as its int16 samples; scaled by 1/32768 they are the float
+    path's samples bit for bit, and the pipeline's batch assembly does exactly that."""
+    rng = np.random.default_rng(5)
+    pcm = rng.integers(-32768, 32768, size=48000, dtype=np.int16)
+    path = tmp_path / "mono16.wav"
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm.tobytes())
+    ref = audio.load_audio_16k(path)
+    fast = audio.load_audio_16k(path, keep_int16=True)
+    assert ref.dtype == np.float32 and fast.dtype == np.int16 and fast.shape == ref.shape
+    out = np.empty(ref.shape, dtype=np.float32)
+    np.multiply(fast, np.float32(1.0 / 32768.0), out=out)
+    assert np.array_equal(out, ref)
+    # other layouts keep the float path: stereo, another rate, 8-bit
+    for ch, rate, width in ((2, 16000, 2), (1, 8000, 2), (1, 16000, 1)):
+        p2 = tmp_path / f"v{ch}_{rate}_{width}.wav"
+        with wave.open(str(p2), "wb") as w:
+            w.setnchannels(ch); w.setsampwidth(width); w.setframerate(rate)
+            w.writeframes(pcm[:3200 * ch].tobytes() if width == 2 else (pcm[:3200] >> 8).astype(np.int8).view(np.uint8).tobytes())
+        assert audio.load_audio_16k(p2, keep_int16=True).dtype == np.float32
+
+
+def test_pipeline_records_do_not_depend_on_the_sample_container(tmp_path, tiny_engine):
+    """The same file through the pipeline with int16 samples kept (default) and with float samples handed in."""
+    from omnilingual_asr.models.inference.asr_pipeline import GeminiASRPipeline
+    rng = np.random.default_rng(6)
+    t = np.arange(16000 * 3)
+    pcm = (2000 * rng.standard_normal(t.size) + 8000 * np.sin(t * 2 * np.pi * 300 / 16000)).astype(np.int16)
+    path = tmp_path / "three_seconds.wav"
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm.tobytes())
+    pipe = GeminiASRPipeline(model="GTINY", engine=tiny_engine, chunk_seconds=1.0, min_chunking_seconds=1.0)
+    kept = pipe._load_audio(path)
+    assert kept.dtype == np.int16
+    a = pipe._encode_chunks(kept, np.array([[0, 16000], [16000, 32000], [32000, 48000]]))
+    b = pipe._encode_chunks(audio.load_audio_16k(path), np.array([[0, 16000], [16000, 32000], [32000, 48000]]))
+    assert len(a) == len(b) == 3
+    for ra, rb in zip(a, b):
+        assert (ra.chunk_idx, ra.start_sample, ra.end_sample, ra.n_frames) == (rb.chunk_idx, rb.start_sample, rb.end_sample, rb.n_frames)
+        assert (ra.tokens is None and rb.tokens is None) or (np.array_equal(ra.tokens, rb.tokens) and np.array_equal(ra.frames, rb.frames))

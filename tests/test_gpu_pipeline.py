@@ -54,6 +54,26 @@ def test_chunked_transcribe_on_hip(tmp_path):
     assert [r.n_frames for r in recs] == [1499, 1499, 1499, 524]
 
 
+def test_int16_samples_kept_as_read_give_the_same_tokens(tmp_path):
+    """A mono 16-bit WAV at 16 kHz stays int16 until batch assembly (scaled while copied); the device
+    results equal those of the float samples bit for bit."""
+    from omnilingual_asr import Pipeline, audio
+
+    wav = tmp_path / "speechlike.wav"
+    _write_wav(wav, 70.25, seed=3)
+    pipe = Pipeline(model="GTINY", batch_size=2).gemini
+    kept = pipe._load_audio(wav)
+    assert kept.dtype == np.int16
+    flt = audio.load_audio_16k(wav)
+    bounds = np.array([[0, 480000], [480000, 960000], [960000, kept.shape[0]]])
+    a, b = pipe._encode_chunks(kept, bounds), pipe._encode_chunks(flt, bounds)
+    assert len(a) == len(b) == 3
+    for ra, rb in zip(a, b):
+        assert ra.n_frames == rb.n_frames
+        assert np.array_equal(ra.tokens, rb.tokens) and np.array_equal(ra.frames, rb.frames)
+    assert sum(len(r.tokens) for r in a) > 0
+
+
 def test_reference_chunk_constants_run_on_the_device(tmp_path, golden_dir):
     """The reference's own plan — 300 s chunks behind the 360 s gate (ref gemini_pipeline.py:217-219,
     :243-310, :713-714) — through the HIP engine: a 601 s file gives the chunk starts the reference

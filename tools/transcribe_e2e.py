@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""What a caller of the public API sees: `Pipeline.transcribe_with_retry(path)` on a long 16 kHz mono WAV written
+to local disk (synthetic noise + tone), end to end - file read, decode, chunk plan, device path, CTC stage,
+segments - with the time spent in audio loading shown separately.  Usage: transcribe_e2e.py [hours]"""
+import sys, time, wave, tempfile, os
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "omnilingual-asr_amd"))
+import numpy as np
+from omnilingual_asr.models.inference.asr_pipeline import GeminiASRPipeline
+
+hours = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
+n = int(hours * 3600 * 16000)
+rng = np.random.default_rng(0)
+t = np.arange(n, dtype=np.float32)
+pcm = (3000 * rng.standard_normal(n).astype(np.float32) + 6000 * np.sin(t * (2 * np.pi * 440 / 16000))).astype(np.int16)
+path = os.path.join(tempfile.gettempdir(), "oasr_e2e.wav")
+with wave.open(path, "wb") as w:
+    w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm.tobytes())
+del pcm, t
+pipe = GeminiASRPipeline(model="G300")
+load_s = [0.0]
+orig = pipe._load_audio
+def timed_load(p):
+    t0 = time.perf_counter()
+    out = orig(p)
+    load_s[0] += time.perf_counter() - t0
+    return out
+pipe._load_audio = timed_load
+for rep in range(3):
+    load_s[0] = 0.0
+    t0 = time.perf_counter()
+    res = pipe.transcribe_with_retry(path)
+    dt = time.perf_counter() - t0
+    print("run %d: %.2f h -> %.3f s wall (audio loading %.3f s) = RTF %.0fx; %d segments" %
+          (rep, hours, dt, load_s[0], hours * 3600 / dt, len(res.segments)), flush=True)
+os.remove(path)
