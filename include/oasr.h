@@ -359,6 +359,12 @@ int oasr_resample_poly(const float* x, int64_t n_in, int64_t x_stride, int32_t b
                        const double* hp, int32_t up, int32_t down, int32_t taps, int32_t half,
                        float* y, int64_t n_out, int64_t y_stride, void* stream);
 
+/* Interleaved 16-bit PCM (as a WAV file holds it; the formats the reference accepts are listed at
+ * ref:src/omnilingual_asr/models/inference/gemini_pipeline.py:106-118) -> mono float32 in [-1, 1) on the device:
+ * out[f] = (sum over channels of pcm[f * channels + c]) / (32768 * channels), the integer sum exact, one rounding
+ * from float64.  pcm int16 [frames * channels] (2-byte aligned), out float32 [frames]; channels in 1..64. */
+int oasr_pcm16_to_mono_f32(const int16_t* pcm, int64_t frames, int32_t channels, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

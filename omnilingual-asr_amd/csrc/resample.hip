@@ -35,9 +35,35 @@ __global__ __launch_bounds__(256) void resample_poly_kernel(const float* __restr
     y[(int64_t)blockIdx.y * y_stride + n] = (float)acc;
 }
 
+// Interleaved 16-bit PCM -> mono float32 in [-1, 1): out[f] = (sum over channels of pcm[f][c]) / (32768 * channels).
+// The integer sum is exact and the quotient is rounded once, from float64 - the value the host path gets from
+// float32 samples averaged in float64.  A thread produces one frame; HBM-bound: 2 * channels bytes in, 4 out.
+__global__ __launch_bounds__(256) void pcm16_to_mono_kernel(const int16_t* __restrict__ pcm, int64_t frames,
+                                                            int channels, float* __restrict__ out) {
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= frames) return;
+    const int16_t* p = pcm + f * channels;
+    int sum = 0;
+    for (int c = 0; c < channels; ++c) sum += p[c];
+    out[f] = (float)((double)sum / (32768.0 * channels));
+}
+
 }  // namespace oasr
 
 using namespace oasr;
+
+extern "C" int oasr_pcm16_to_mono_f32(const int16_t* pcm, int64_t frames, int32_t channels, float* out, void* stream) {
+    OASR_REQUIRE(pcm && out, "pcm16_to_mono: null pointer");
+    OASR_REQUIRE(frames >= 0 && channels >= 1 && channels <= 64, "pcm16_to_mono: frames=%lld must be >= 0 and channels=%d in 1..64",
+                 (long long)frames, channels);
+    if (frames == 0) return OASR_OK;
+    const int64_t blocks = (frames + 255) / 256;
+    OASR_REQUIRE(blocks < ((int64_t)1 << 31), "pcm16_to_mono: too many frames per launch");
+    hipLaunchKernelGGL(pcm16_to_mono_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pcm, frames,
+                       channels, out);
+    OASR_CHECK_LAUNCH("pcm16_to_mono");
+    return OASR_OK;
+}
 
 extern "C" int64_t oasr_resample_length(int64_t n_in, int32_t up, int32_t down) {
     if (n_in < 0 || up <= 0 || down <= 0) return -1;

@@ -79,10 +79,10 @@ def read_wav(path) -> tuple[np.ndarray, int]:
     return x.reshape(n, channels), int(rate)
 
 
-def read_wav_pcm16_mono(path):
-    """(int16 [frames] view of the memory-mapped file, sample_rate) when `path` is a mono 16-bit PCM WAV, else
-    None.  The sample value in [-1, 1) is the integer / 32768; nothing is read, converted or copied here: the
-    pages are touched when chunks are copied into batches."""
+def map_wav_pcm16(path):
+    """(int16 [frames * channels] interleaved view of the memory-mapped file, channels, sample_rate) when `path`
+    is a 16-bit PCM WAV, else None.  A sample's value in [-1, 1) is the integer / 32768; nothing is read,
+    converted or copied here: the pages are touched when the samples are used."""
     import mmap
     with open(path, "rb") as f:
         size = f.seek(0, 2)
@@ -106,9 +106,16 @@ def read_wav_pcm16_mono(path):
     tag, channels, rate, _, block, bits = struct.unpack_from("<HHIIHH", fmt, 0)
     if tag == 0xFFFE and len(fmt) >= 26:
         tag = struct.unpack_from("<H", fmt, 24)[0]
-    if tag != 1 or channels != 1 or bits != 16 or block != 2:
+    if tag != 1 or bits != 16 or channels < 1 or channels > 64 or block != 2 * channels or rate < 1:
         return None
-    return np.frombuffer(mm, dtype="<i2", count=data_len // 2, offset=data_at), int(rate)
+    frames = data_len // block
+    return np.frombuffer(mm, dtype="<i2", count=frames * channels, offset=data_at), int(channels), int(rate)
+
+
+def read_wav_pcm16_mono(path):
+    """(int16 [frames], sample_rate) when `path` is a mono 16-bit PCM WAV (see `map_wav_pcm16`), else None."""
+    m = map_wav_pcm16(path)
+    return (m[0], m[2]) if m is not None and m[1] == 1 else None
 
 
 def wav_duration(path) -> float:

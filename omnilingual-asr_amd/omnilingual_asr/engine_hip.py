@@ -49,6 +49,7 @@ class HipEngine:
         self._tickets: dict = {}
         self._copy_stream = None
         self.use_graphs = use_graphs
+        self._pcm16_stage = None
         self.max_buffer_sets = 6        # distinct (batch, padded length) shapes kept resident
 
     # ---- set-up ---------------------------------------------------------------------------------------
@@ -226,6 +227,38 @@ class HipEngine:
                                             half, y.data_ptr(), n_out, n_out, _hip.current_stream_ptr()),
                        "oasr_resample_poly")
         return y[0] if squeeze else y
+
+    def pcm16_to_16k(self, interleaved: np.ndarray, channels: int, rate_in: int) -> np.ndarray:
+        """Interleaved int16 samples as a WAV file holds them (e.g. a memory-mapped file) -> mono float32 at
+        16 kHz on the host.  The file's bytes go to the device through two page-locked staging blocks, the
+        down-mix / conversion and the rate conversion run there, and only the 16 kHz signal comes back - the
+        host never holds a float copy of the file at its own rate.  Equal, bit for bit, to decoding on the
+        host (float32 samples, channels averaged in float64) followed by `resample_16k`."""
+        x = np.asarray(interleaved)
+        if x.dtype != np.int16 or x.ndim != 1 or channels < 1 or x.shape[0] % channels:
+            raise ValueError("pcm16_to_16k wants a flat int16 array of frames * channels samples")
+        total, frames = int(x.shape[0]), int(x.shape[0]) // int(channels)
+        if frames == 0:
+            return np.zeros((0,), dtype=np.float32)
+        block = 1 << 25                                                  # 64 MiB of samples per staging block
+        with torch.cuda.device(self.device):
+            raw = torch.empty((total,), dtype=torch.int16, device=self.device)
+            if self._pcm16_stage is None:
+                self._pcm16_stage = [torch.empty((block,), dtype=torch.int16).pin_memory() for _ in range(2)]
+            events = [torch.cuda.Event(), torch.cuda.Event()]
+            for i, off in enumerate(range(0, total, block)):
+                n = min(block, total - off)
+                stage = self._pcm16_stage[i & 1]
+                if i >= 2:
+                    events[i & 1].synchronize()                          # the block's previous copy has left it
+                stage.numpy()[:n] = x[off: off + n]
+                raw[off: off + n].copy_(stage[:n], non_blocking=True)
+                events[i & 1].record()
+            mono = torch.empty((frames,), dtype=torch.float32, device=self.device)
+            _hip.check(_hip.lib().oasr_pcm16_to_mono_f32(raw.data_ptr(), frames, int(channels), mono.data_ptr(),
+                                                         _hip.current_stream_ptr()), "oasr_pcm16_to_mono_f32")
+            del raw
+            return self.resample_16k(mono, rate_in).cpu().numpy()
 
     def decode(self, hidden: torch.Tensor, lengths: torch.Tensor, buf=None):
         """Encoder states float32 [B, t_pad, d] (as returned by `encode_features`) and lengths int32 [B]

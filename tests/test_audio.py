@@ -111,3 +111,22 @@ def test_pipeline_records_do_not_depend_on_the_sample_container(tmp_path, tiny_e
     for ra, rb in zip(a, b):
         assert (ra.chunk_idx, ra.start_sample, ra.end_sample, ra.n_frames) == (rb.chunk_idx, rb.start_sample, rb.end_sample, rb.n_frames)
         assert (ra.tokens is None and rb.tokens is None) or (np.array_equal(ra.tokens, rb.tokens) and np.array_equal(ra.frames, rb.frames))
+
+
+def test_map_wav_pcm16_layouts(tmp_path):
+    """16-bit PCM WAVs of any channel count are mapped as interleaved int16; other widths are not."""
+    rng = np.random.default_rng(7)
+    pcm = rng.integers(-32768, 32768, size=3 * 4410, dtype=np.int16)
+    p3 = tmp_path / "three.wav"
+    with wave.open(str(p3), "wb") as w:
+        w.setnchannels(3); w.setsampwidth(2); w.setframerate(44100); w.writeframes(pcm.tobytes())
+    samples, channels, rate = audio.map_wav_pcm16(p3)
+    assert (channels, rate) == (3, 44100) and np.array_equal(samples, pcm)
+    x, r = audio.read_wav(p3)
+    assert np.array_equal(samples.reshape(-1, 3).astype(np.float32) / 32768.0, x) and r == rate
+    p8 = tmp_path / "eight.wav"
+    with wave.open(str(p8), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(1); w.setframerate(16000); w.writeframes(bytes(range(200)))
+    assert audio.map_wav_pcm16(p8) is None
+    (tmp_path / "short.wav").write_bytes(b"RIFF")
+    assert audio.map_wav_pcm16(tmp_path / "short.wav") is None

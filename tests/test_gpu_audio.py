@@ -46,3 +46,33 @@ def test_pipeline_uses_device_resampler(golden_dir):
     ref = audio.load_audio_16k(golden_dir / "gettysburg.wav")
     assert got.shape == ref.shape == (281233,)
     np.testing.assert_allclose(got, ref, rtol=0, atol=1.2e-7)
+
+
+@pytest.mark.parametrize("channels,rate", [(2, 48000), (1, 44100), (2, 16000), (3, 22050)])
+def test_pcm16_files_decoded_on_the_device_equal_the_host_decode(tmp_path, channels, rate):
+    """16-bit WAVs go to the device as the file holds them (down-mix, conversion and rate conversion there);
+    the 16 kHz signal equals host decoding + the same device resampler bit for bit."""
+    import wave
+    from omnilingual_asr import Pipeline, audio
+
+    rng = np.random.default_rng(11)
+    frames = int(rate * 2.37)
+    pcm = rng.integers(-32768, 32768, size=frames * channels, dtype=np.int16)
+    path = tmp_path / "x.wav"
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(channels); w.setsampwidth(2); w.setframerate(rate); w.writeframes(pcm.tobytes())
+    pipe = Pipeline(model="GTINY").gemini
+    got = pipe._load_audio(path)
+    want = audio.load_audio_16k(path, lambda mono, r: pipe.engine.resample_16k(mono, r).cpu().numpy())
+    assert got.dtype == np.float32 and got.shape == want.shape
+    assert np.array_equal(got, want)
+
+
+def test_gettysburg_fixture_through_the_device_decode(golden_dir):
+    from omnilingual_asr import Pipeline, audio
+
+    pipe = Pipeline(model="GTINY").gemini
+    path = golden_dir / "gettysburg.wav"
+    got = pipe._load_audio(path)
+    want = audio.load_audio_16k(path, lambda mono, r: pipe.engine.resample_16k(mono, r).cpu().numpy())
+    assert np.array_equal(got, want)

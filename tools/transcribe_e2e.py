@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """What a caller of the public API sees: `Pipeline.transcribe_with_retry(path)` on a long 16 kHz mono WAV written
 to local disk (synthetic noise + tone), end to end - file read, decode, chunk plan, device path, CTC stage,
-segments - with the time spent in audio loading shown separately.  Usage: transcribe_e2e.py [hours]"""
+segments - with the time spent in audio loading shown separately.  Usage: transcribe_e2e.py [hours [rate [channels]]]"""
 import sys, time, wave, tempfile, os
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -10,13 +10,16 @@ import numpy as np
 from omnilingual_asr.models.inference.asr_pipeline import GeminiASRPipeline
 
 hours = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
-n = int(hours * 3600 * 16000)
+rate = int(sys.argv[2]) if len(sys.argv) > 2 else 16000
+channels = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+n = int(hours * 3600 * rate)
 rng = np.random.default_rng(0)
 t = np.arange(n, dtype=np.float32)
-pcm = (3000 * rng.standard_normal(n).astype(np.float32) + 6000 * np.sin(t * (2 * np.pi * 440 / 16000))).astype(np.int16)
+pcm = (3000 * rng.standard_normal(n).astype(np.float32) + 6000 * np.sin(t * (2 * np.pi * 440 / rate))).astype(np.int16)
 path = os.path.join(tempfile.gettempdir(), "oasr_e2e.wav")
 with wave.open(path, "wb") as w:
-    w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(pcm.tobytes())
+    w.setnchannels(channels); w.setsampwidth(2); w.setframerate(rate)
+    w.writeframes(pcm.tobytes() if channels == 1 else np.repeat(pcm, channels).tobytes())
 del pcm, t
 pipe = GeminiASRPipeline(model="G300")
 load_s = [0.0]
