@@ -258,12 +258,19 @@ int oasr_gemm_bf16_ex(const uint16_t* a, const uint16_t* w, const float* bias, c
 /* FLAC decode on the host (the reference accepts .flac uploads and forwards the bytes to its remote
  * model: ref gemini_pipeline.py:106-118, workflows/wav2elan_web/app.py:76-77).  oasr_flac_info reads
  * STREAMINFO (md5_16 may be NULL; a sample count missing from the header is found by decoding);
- * oasr_flac_decode writes interleaved samples, sign-extended to int32 at the stream's bit depth.
- * Frame header CRC-8 and frame CRC-16 are verified. */
+ * oasr_flac_decode writes interleaved samples, sign-extended to int32 at the stream's bit depth;
+ * oasr_flac_decode16 (streams of at most 16 bits per sample) writes them as int16 scaled to 16 bits, i.e.
+ * sample / 32768 is the value in [-1, 1) - the form oasr_pcm16_to_mono_f32 takes.
+ * Frame header CRC-8 and frame CRC-16 are verified.  Streams of a fixed block size with a known sample
+ * count are decoded by up to 16 host threads, each on a byte range (a thread starts at the first position
+ * of its range where a whole frame decodes and checks, and the ranges must chain byte for byte and sample for
+ * sample, else the stream is decoded again in order); OASR_FLAC_THREADS in the environment overrides the count. */
 int oasr_flac_info(const uint8_t* data, int64_t size, int32_t* sample_rate, int32_t* channels,
                    int32_t* bits, int64_t* samples_per_channel, uint8_t* md5_16);
 int oasr_flac_decode(const uint8_t* data, int64_t size, int32_t* out, int64_t capacity_per_channel,
                      int64_t* written_per_channel);
+int oasr_flac_decode16(const uint8_t* data, int64_t size, int16_t* out, int64_t capacity_per_channel,
+                       int64_t* written_per_channel);
 
 /* LayerNorm (optionally followed by Swish) straight to e4m3 rows + per-row scale: byte-identical to
  * oasr_layernorm(out_bf16=1) followed by oasr_quant_fp8_rows, without the intermediate bf16 matrix.

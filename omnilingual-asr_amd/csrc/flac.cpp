@@ -5,8 +5,10 @@
 // CONSTANT / VERBATIM / FIXED / LPC subframes, both Rice residual codings with escape partitions, wasted
 // bits, the three stereo decorrelations, frame CRC-16.  Output: interleaved int32 samples.
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <thread>
 #include <vector>
 
 #include "oasr_common.h"
@@ -22,6 +24,13 @@ struct BitReader {
     bool bad = false;
     BitReader(const uint8_t* d, size_t len) : p(d), n(len) {}
     void fill() {
+        if (bits <= 32 && pos + 4 <= n) {   // four bytes at once while they last
+            uint32_t w;
+            memcpy(&w, p + pos, 4);
+            acc = (acc << 32) | __builtin_bswap32(w);
+            pos += 4;
+            bits += 32;
+        }
         while (bits <= 56 && pos < n) {
             acc = (acc << 8) | p[pos++];
             bits += 8;
@@ -67,25 +76,57 @@ struct BitReader {
             return q;
         }
     }
+    // One Rice-coded value: unary quotient, a 1 bit, `param` (< 32) low bits; the zig-zag fold is the caller's.
+    // Fast path: the whole code lies in the bits already loaded (the common case: the refill leaves >= 57).
+    uint64_t rice(int param) {
+        fill();
+        if (bits > 0) {
+            const uint64_t window = acc << (64 - bits);   // valid bits at the top
+            if (window != 0) {
+                const int z = __builtin_clzll(window);
+                const int used = z + 1 + param;
+                if (used <= bits) {
+                    const uint64_t low = param ? ((window << (z + 1)) >> (64 - param)) : 0;
+                    bits -= used;
+                    return ((uint64_t)z << param) | low;
+                }
+            }
+        }
+        const uint64_t q = unary();
+        return (q << param) | get(param);
+    }
     void align() { bits -= bits & 7; }
     size_t byte_pos() const { return pos - bits / 8; }   // only meaningful when aligned
 };
 
+// CRC-8 (polynomial 0x07) and CRC-16 (0x8005), MSB first, one table look-up per byte.
+struct CrcTables {
+    uint8_t t8[256];
+    uint16_t t16[256];
+    CrcTables() {
+        for (int v = 0; v < 256; ++v) {
+            uint8_t c = (uint8_t)v;
+            uint16_t w = (uint16_t)(v << 8);
+            for (int b = 0; b < 8; ++b) {
+                c = (c & 0x80) ? (uint8_t)((c << 1) ^ 0x07) : (uint8_t)(c << 1);
+                w = (w & 0x8000) ? (uint16_t)((w << 1) ^ 0x8005) : (uint16_t)(w << 1);
+            }
+            t8[v] = c;
+            t16[v] = w;
+        }
+    }
+};
+static const CrcTables kCrc;
+
 static uint8_t crc8(const uint8_t* d, size_t n) {
     uint8_t c = 0;
-    for (size_t i = 0; i < n; ++i) {
-        c ^= d[i];
-        for (int b = 0; b < 8; ++b) c = (c & 0x80) ? (uint8_t)((c << 1) ^ 0x07) : (uint8_t)(c << 1);
-    }
+    for (size_t i = 0; i < n; ++i) c = kCrc.t8[c ^ d[i]];
     return c;
 }
 
 static uint16_t crc16(const uint8_t* d, size_t n) {
     uint16_t c = 0;
-    for (size_t i = 0; i < n; ++i) {
-        c ^= (uint16_t)(d[i] << 8);
-        for (int b = 0; b < 8; ++b) c = (c & 0x8000) ? (uint16_t)((c << 1) ^ 0x8005) : (uint16_t)(c << 1);
-    }
+    for (size_t i = 0; i < n; ++i) c = (uint16_t)((c << 8) ^ kCrc.t16[(c >> 8) ^ d[i]]);
     return c;
 }
 
@@ -164,14 +205,39 @@ static bool read_residual(BitReader& br, int64_t* out, int blocksize, int pred_o
             for (int i = 0; i < count; ++i) out[idx++] = nb ? br.get_signed(nb) : 0;
         } else {
             for (int i = 0; i < count; ++i) {
-                const uint32_t q = br.unary();
-                const uint64_t u = ((uint64_t)q << param) | br.get(param);
+                const uint64_t u = br.rice(param);
                 out[idx++] = (int64_t)(u >> 1) ^ -(int64_t)(u & 1);
             }
         }
         if (br.bad) return false;
     }
     return idx == blocksize - pred_order;
+}
+
+// s[i] += (sum_j coef[j] * s[i - 1 - j]) >> shift for i >= ORDER: the order is a compile-time constant for the
+// orders encoders use, so the inner sum is straight-line code.
+template <int ORDER>
+static void lpc_restore_n(int64_t* s, int blocksize, const int64_t* coef, int shift) {
+    for (int i = ORDER; i < blocksize; ++i) {
+        int64_t acc = 0;
+#pragma GCC unroll 32
+        for (int j = 0; j < ORDER; ++j) acc += coef[j] * s[i - 1 - j];
+        s[i] += acc >> shift;
+    }
+}
+static void lpc_restore(int64_t* s, int blocksize, int order, const int64_t* coef, int shift) {
+    switch (order) {
+#define OASR_LPC_CASE(N) case N: lpc_restore_n<N>(s, blocksize, coef, shift); return;
+        OASR_LPC_CASE(1) OASR_LPC_CASE(2) OASR_LPC_CASE(3) OASR_LPC_CASE(4) OASR_LPC_CASE(5) OASR_LPC_CASE(6)
+        OASR_LPC_CASE(7) OASR_LPC_CASE(8) OASR_LPC_CASE(9) OASR_LPC_CASE(10) OASR_LPC_CASE(11) OASR_LPC_CASE(12)
+#undef OASR_LPC_CASE
+        default: break;
+    }
+    for (int i = order; i < blocksize; ++i) {
+        int64_t acc = 0;
+        for (int j = 0; j < order; ++j) acc += coef[j] * s[i - 1 - j];
+        s[i] += acc >> shift;
+    }
 }
 
 static bool read_subframe(BitReader& br, int64_t* s, int blocksize, int bps) {
@@ -213,11 +279,7 @@ static bool read_subframe(BitReader& br, int64_t* s, int blocksize, int bps) {
         int64_t coef[32];
         for (int j = 0; j < order; ++j) coef[j] = br.get_signed(prec);
         if (!read_residual(br, s + order, blocksize, order)) return false;
-        for (int i = order; i < blocksize; ++i) {
-            int64_t acc = 0;
-            for (int j = 0; j < order; ++j) acc += coef[j] * s[i - 1 - j];
-            s[i] += acc >> shift;
-        }
+        lpc_restore(s, blocksize, order, coef, shift);
     } else {
         return false;   // reserved subframe type
     }
@@ -226,80 +288,123 @@ static bool read_subframe(BitReader& br, int64_t* s, int blocksize, int bps) {
     return !br.bad;
 }
 
-// Decodes every frame; returns samples per channel written (<= capacity), or a negative status.
-static int64_t decode(const uint8_t* d, size_t n, const StreamInfo& si, int32_t* out, int64_t capacity) {
+// One frame at d[pos..]: header (sync, CRC-8), subframes, CRC-16, stereo reconstruction.  On success returns
+// the frame's length in bytes and fills `blocksize`, `first_sample` (from the coded frame / sample number) and
+// ch[c][0..blocksize).  On failure returns 0 and, if `why` is given, a short reason (no error state is set here:
+// this also runs in worker threads and on candidate positions that turn out not to be frames).
+struct FrameScratch {
+    std::vector<int64_t> ch[8];
+};
+static size_t decode_frame(const uint8_t* d, size_t n, size_t pos, const StreamInfo& si, FrameScratch& fs,
+                           int& blocksize, int64_t& first_sample, int& nch_out, const char** why) {
     static const int kBlock[16] = {0, 192, 576, 1152, 2304, 4608, -8, -16, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768};
     static const int kBits[8] = {0, 8, 12, -1, 16, 20, 24, 32};
+    auto fail = [&](const char* msg) {
+        if (why) *why = msg;
+        return (size_t)0;
+    };
+    if (pos + 6 > n || !(d[pos] == 0xFF && (d[pos + 1] & 0xFE) == 0xF8)) return fail("lost frame sync");
+    const bool variable = d[pos + 1] & 1;   // blocking strategy: the coded number counts samples, not frames
+    BitReader br(d + pos, n - pos);
+    br.get(16);
+    const int bs_code = (int)br.get(4), sr_code = (int)br.get(4);
+    const int ch_code = (int)br.get(4), bits_code = (int)br.get(3);
+    if (br.get(1) || bs_code == 0 || sr_code == 15 || ch_code > 10 || kBits[bits_code] < 0)
+        return fail("reserved field in a frame header");
+    uint64_t number;
+    {   // frame or sample number, "UTF-8" coded, up to 36 bits
+        const uint32_t b0 = br.get(8);
+        int extra = 0;
+        if (b0 >= 0xFE) extra = 6;
+        else if (b0 >= 0xFC) extra = 5;
+        else if (b0 >= 0xF8) extra = 4;
+        else if (b0 >= 0xF0) extra = 3;
+        else if (b0 >= 0xE0) extra = 2;
+        else if (b0 >= 0xC0) extra = 1;
+        else if (b0 >= 0x80) return fail("malformed frame number");
+        number = extra ? (b0 & (0x3Fu >> extra)) : b0;
+        for (int i = 0; i < extra; ++i) {
+            const uint32_t bx = br.get(8);
+            if ((bx & 0xC0) != 0x80) return fail("malformed frame number");
+            number = (number << 6) | (bx & 0x3F);
+        }
+    }
+    blocksize = kBlock[bs_code];
+    if (blocksize == -8) blocksize = (int)br.get(8) + 1;
+    else if (blocksize == -16) blocksize = (int)br.get(16) + 1;
+    if (sr_code == 12) br.get(8);
+    else if (sr_code == 13 || sr_code == 14) br.get(16);
+    const size_t hdr_len = br.byte_pos();
+    const uint32_t want8 = br.get(8);
+    if (br.bad || crc8(d + pos, hdr_len) != want8) return fail("frame header CRC mismatch");
+    const int bps = kBits[bits_code] ? kBits[bits_code] : si.bits;
+    const int nch = ch_code < 8 ? ch_code + 1 : 2;
+    if (nch != si.channels) return fail("channel count changes inside the stream");
+    first_sample = variable ? (int64_t)number : (int64_t)number * si.max_block;
+    nch_out = nch;
+    for (int c = 0; c < nch; ++c) {
+        fs.ch[c].resize(blocksize);
+        const int side = (ch_code == 8 && c == 1) || (ch_code == 9 && c == 0) || (ch_code == 10 && c == 1);
+        if (!read_subframe(br, fs.ch[c].data(), blocksize, bps + side)) return fail("malformed subframe");
+    }
+    br.align();
+    const size_t body_len = br.byte_pos();
+    const uint32_t want16 = br.get(16);
+    if (br.bad || crc16(d + pos, body_len) != want16) return fail("frame CRC mismatch");
+    int64_t* c0 = fs.ch[0].data();
+    int64_t* c1 = fs.ch[1].data();
+    if (ch_code == 8) {
+        for (int i = 0; i < blocksize; ++i) c1[i] = c0[i] - c1[i];
+    } else if (ch_code == 9) {
+        for (int i = 0; i < blocksize; ++i) c0[i] = c1[i] + c0[i];
+    } else if (ch_code == 10) {
+        for (int i = 0; i < blocksize; ++i) {
+            const int64_t side = c1[i], mid = c0[i] * 2 + (side & 1);
+            c0[i] = (mid + side) >> 1;
+            c1[i] = (mid - side) >> 1;
+        }
+    }
+    return br.byte_pos();
+}
+
+// Where decoded samples go: interleaved int32 at the stream's bit depth, or interleaved int16 scaled to 16 bits
+// (streams of at most 16 bits per sample; value << (16 - bits), so that sample / 32768 is the same number).
+struct Sink {
+    int32_t* o32 = nullptr;
+    int16_t* o16 = nullptr;
+    int shift = 0;
+    explicit operator bool() const { return o32 || o16; }
+};
+static void emit(const FrameScratch& fs, int nch, int64_t take, const Sink& sk, int64_t at) {
+    if (sk.o16) {
+        int16_t* dst = sk.o16 + at * nch;
+        for (int c = 0; c < nch; ++c) {
+            const int64_t* src = fs.ch[c].data();
+            for (int64_t i = 0; i < take; ++i) dst[i * nch + c] = (int16_t)(src[i] << sk.shift);
+        }
+    } else {
+        int32_t* dst = sk.o32 + at * nch;
+        for (int c = 0; c < nch; ++c) {
+            const int64_t* src = fs.ch[c].data();
+            for (int64_t i = 0; i < take; ++i) dst[i * nch + c] = (int32_t)src[i];
+        }
+    }
+}
+
+// Decodes every frame in order; returns samples per channel written (<= capacity), or a negative status.
+static int64_t decode(const uint8_t* d, size_t n, const StreamInfo& si, const Sink& out, int64_t capacity) {
     size_t pos = si.audio_start;
     int64_t done = 0;
-    std::vector<int64_t> ch[8];
+    FrameScratch fs;
     while (pos + 2 <= n) {
-        if (!(d[pos] == 0xFF && (d[pos + 1] & 0xFE) == 0xF8)) {
+        int blocksize = 0, nch = 0;
+        int64_t first = 0;
+        const char* why = "";
+        const size_t len = decode_frame(d, n, pos, si, fs, blocksize, first, nch, &why);
+        if (len == 0) {
             if (si.total && done >= si.total) break;   // trailing bytes after the last frame
-            set_error("flac: lost frame sync at byte %zu", pos);
+            set_error("flac: %s at byte %zu", why, pos);
             return OASR_EINVAL;
-        }
-        BitReader br(d + pos, n - pos);
-        br.get(16);
-        const int bs_code = (int)br.get(4), sr_code = (int)br.get(4);
-        const int ch_code = (int)br.get(4), bits_code = (int)br.get(3);
-        if (br.get(1) || bs_code == 0 || sr_code == 15 || ch_code > 10 || kBits[bits_code] < 0) {
-            set_error("flac: reserved field in a frame header at byte %zu", pos);
-            return OASR_EINVAL;
-        }
-        {   // frame or sample number, "UTF-8" coded, up to 36 bits: only skipped
-            const uint32_t b0 = br.get(8);
-            int extra = 0;
-            if (b0 >= 0xFE) extra = 6;
-            else if (b0 >= 0xFC) extra = 5;
-            else if (b0 >= 0xF8) extra = 4;
-            else if (b0 >= 0xF0) extra = 3;
-            else if (b0 >= 0xE0) extra = 2;
-            else if (b0 >= 0xC0) extra = 1;
-            for (int i = 0; i < extra; ++i) br.get(8);
-        }
-        int blocksize = kBlock[bs_code];
-        if (blocksize == -8) blocksize = (int)br.get(8) + 1;
-        else if (blocksize == -16) blocksize = (int)br.get(16) + 1;
-        if (sr_code == 12) br.get(8);
-        else if (sr_code == 13 || sr_code == 14) br.get(16);
-        const size_t hdr_len = br.byte_pos();
-        const uint32_t want8 = br.get(8);
-        if (br.bad || crc8(d + pos, hdr_len) != want8) {
-            set_error("flac: frame header CRC mismatch at byte %zu", pos);
-            return OASR_EINVAL;
-        }
-        const int bps = kBits[bits_code] ? kBits[bits_code] : si.bits;
-        const int nch = ch_code < 8 ? ch_code + 1 : 2;
-        if (nch != si.channels) {
-            set_error("flac: channel count changes inside the stream");
-            return OASR_EINVAL;
-        }
-        for (int c = 0; c < nch; ++c) {
-            ch[c].resize(blocksize);
-            const int side = (ch_code == 8 && c == 1) || (ch_code == 9 && c == 0) || (ch_code == 10 && c == 1);
-            if (!read_subframe(br, ch[c].data(), blocksize, bps + side)) {
-                set_error("flac: malformed subframe in the frame at byte %zu", pos);
-                return OASR_EINVAL;
-            }
-        }
-        br.align();
-        const size_t body_len = br.byte_pos();
-        const uint32_t want16 = br.get(16);
-        if (br.bad || crc16(d + pos, body_len) != want16) {
-            set_error("flac: frame CRC mismatch at byte %zu", pos);
-            return OASR_EINVAL;
-        }
-        if (ch_code == 8) {
-            for (int i = 0; i < blocksize; ++i) ch[1][i] = ch[0][i] - ch[1][i];
-        } else if (ch_code == 9) {
-            for (int i = 0; i < blocksize; ++i) ch[0][i] = ch[1][i] + ch[0][i];
-        } else if (ch_code == 10) {
-            for (int i = 0; i < blocksize; ++i) {
-                const int64_t side = ch[1][i], mid = ch[0][i] * 2 + (side & 1);
-                ch[0][i] = (mid + side) >> 1;
-                ch[1][i] = (mid - side) >> 1;
-            }
         }
         int64_t take = blocksize;
         if (si.total && done + take > si.total) take = si.total - done;
@@ -308,13 +413,87 @@ static int64_t decode(const uint8_t* d, size_t n, const StreamInfo& si, int32_t*
                 set_error("flac: output holds %lld samples per channel, stream has more", (long long)capacity);
                 return OASR_ECAPACITY;
             }
-            for (int64_t i = 0; i < take; ++i)
-                for (int c = 0; c < nch; ++c) out[(done + i) * nch + c] = (int32_t)ch[c][i];
+            emit(fs, nch, take, out, done);
         }
         done += take;
-        pos += br.byte_pos();
+        pos += len;
     }
     return done;
+}
+
+// The same result from several threads.  The bytes after the metadata are cut into equal ranges; a worker
+// finds the first position in its range where a whole frame decodes (sync code, header CRC-8, subframes,
+// CRC-16), decodes on from there until a frame starts at or past the end of its range, and writes each frame
+// at the sample position its header states.  Afterwards the ranges must chain: every worker stopped exactly
+// where the next one started, the first started at the first frame, the last reached the end of the data, and
+// the sample positions are contiguous.  Anything else (a false start inside a frame, a damaged file, a stream
+// without a fixed block size or total) returns -1 and the caller decodes sequentially.
+static int64_t decode_parallel(const uint8_t* d, size_t n, const StreamInfo& si, const Sink& out, int64_t capacity,
+                               int threads) {
+    if (!out || si.total <= 0 || si.total > capacity || si.max_block <= 0 || si.min_block != si.max_block) return -1;
+    const size_t begin = si.audio_start, span = n - begin;
+    struct Part {
+        size_t first = 0, end = 0;          // byte position of the first frame decoded / after the last one
+        int64_t s_first = -1, s_end = -1;   // sample range covered
+        bool ok = false;
+    };
+    std::vector<Part> parts(threads);
+    auto work = [&](int k) {
+        Part& pt = parts[k];
+        const size_t lo = begin + span * k / threads, hi = begin + span * (k + 1) / threads;
+        FrameScratch fs;
+        size_t pos = lo;
+        int blocksize = 0, nch = 0;
+        int64_t first = 0;
+        size_t len = 0;
+        for (; pos < hi; ++pos) {   // first whole frame at or after lo
+            if (d[pos] != 0xFF || pos + 1 >= n || (d[pos + 1] & 0xFE) != 0xF8) continue;
+            len = decode_frame(d, n, pos, si, fs, blocksize, first, nch, nullptr);
+            if (len) break;
+        }
+        if (!len) {                 // no frame starts in this range: an empty part that chains through
+            pt.first = pt.end = hi;
+            pt.ok = true;
+            return;
+        }
+        pt.first = pos;
+        pt.s_first = first;
+        for (;;) {
+            if (first < 0 || first >= si.total) return;                      // not ok
+            const int64_t take = first + blocksize > si.total ? si.total - first : blocksize;
+            emit(fs, nch, take, out, first);
+            pt.s_end = first + take;
+            pos += len;
+            if (pos >= hi || pos + 2 > n) break;
+            len = decode_frame(d, n, pos, si, fs, blocksize, first, nch, nullptr);
+            if (!len) {
+                if (pt.s_end >= si.total) break;                             // trailing bytes after the last frame
+                return;                                                      // not ok
+            }
+            if (first != pt.s_end) return;                                   // not ok
+        }
+        pt.end = pos;
+        pt.ok = true;
+    };
+    std::vector<std::thread> pool;
+    for (int k = 1; k < threads; ++k) pool.emplace_back(work, k);
+    work(0);
+    for (auto& t : pool) t.join();
+    // chain check
+    size_t at = begin;
+    int64_t s_at = 0;
+    for (int k = 0; k < threads; ++k) {
+        const Part& pt = parts[k];
+        if (!pt.ok) return -1;
+        if (pt.s_first < 0) {            // empty part
+            continue;
+        }
+        if (pt.first != at || pt.s_first != s_at) return -1;
+        at = pt.end;
+        s_at = pt.s_end;
+    }
+    if (s_at != si.total) return -1;
+    return si.total;
 }
 
 }  // namespace flac
@@ -331,7 +510,7 @@ int oasr_flac_info(const uint8_t* data, int64_t size, int32_t* sample_rate, int3
     const int rc = flac::parse_header(data, (size_t)size, si);
     if (rc != OASR_OK) return rc;
     if (si.total == 0) {   // unknown in the header (streamed encoders): count by decoding
-        const int64_t n = flac::decode(data, (size_t)size, si, nullptr, 0);
+        const int64_t n = flac::decode(data, (size_t)size, si, flac::Sink{}, 0);
         if (n < 0) return (int)n;
         si.total = n;
     }
@@ -343,16 +522,44 @@ int oasr_flac_info(const uint8_t* data, int64_t size, int32_t* sample_rate, int3
     return OASR_OK;
 }
 
+static int flac_decode_to(const uint8_t* data, int64_t size, const flac::StreamInfo& si, const flac::Sink& sink,
+                          int64_t capacity_per_channel, int64_t* written_per_channel) {
+    // large files: several threads, each on a byte range (at least 1 MiB apiece, at most 16)
+    int threads = (int)std::thread::hardware_concurrency();
+    if (const char* env = getenv("OASR_FLAC_THREADS")) threads = atoi(env);
+    if (threads > 16) threads = 16;
+    const int64_t by_size = (size - (int64_t)si.audio_start) >> 20;
+    if (threads > by_size) threads = (int)by_size;
+    int64_t n = -1;
+    if (threads >= 2) n = flac::decode_parallel(data, (size_t)size, si, sink, capacity_per_channel, threads);
+    if (n < 0) n = flac::decode(data, (size_t)size, si, sink, capacity_per_channel);
+    if (n < 0) return (int)n;
+    *written_per_channel = n;
+    return OASR_OK;
+}
+
 int oasr_flac_decode(const uint8_t* data, int64_t size, int32_t* out, int64_t capacity_per_channel,
                      int64_t* written_per_channel) {
     OASR_REQUIRE(data && size > 0 && out && written_per_channel, "flac_decode: null pointer");
     flac::StreamInfo si;
     const int rc = flac::parse_header(data, (size_t)size, si);
     if (rc != OASR_OK) return rc;
-    const int64_t n = flac::decode(data, (size_t)size, si, out, capacity_per_channel);
-    if (n < 0) return (int)n;
-    *written_per_channel = n;
-    return OASR_OK;
+    flac::Sink sink;
+    sink.o32 = out;
+    return flac_decode_to(data, size, si, sink, capacity_per_channel, written_per_channel);
+}
+
+int oasr_flac_decode16(const uint8_t* data, int64_t size, int16_t* out, int64_t capacity_per_channel,
+                       int64_t* written_per_channel) {
+    OASR_REQUIRE(data && size > 0 && out && written_per_channel, "flac_decode16: null pointer");
+    flac::StreamInfo si;
+    const int rc = flac::parse_header(data, (size_t)size, si);
+    if (rc != OASR_OK) return rc;
+    OASR_REQUIRE(si.bits <= 16, "flac_decode16: the stream has %d bits per sample (at most 16 fit)", si.bits);
+    flac::Sink sink;
+    sink.o16 = out;
+    sink.shift = 16 - si.bits;
+    return flac_decode_to(data, size, si, sink, capacity_per_channel, written_per_channel);
 }
 
 }  // extern "C"

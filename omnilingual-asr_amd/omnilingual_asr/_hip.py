@@ -103,6 +103,7 @@ _SIGNATURES = {
     "oasr_dwconv_ln_swish": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_f32, c_vp]),
     "oasr_flac_info": (c_i32, [c_vp, c_i64, C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_i64), c_vp]),
     "oasr_flac_decode": (c_i32, [c_vp, c_i64, c_vp, c_i64, C.POINTER(c_i64)]),
+    "oasr_flac_decode16": (c_i32, [c_vp, c_i64, c_vp, c_i64, C.POINTER(c_i64)]),
     "oasr_pcm16_to_mono_f32": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp]),
     "oasr_resample_length": (c_i64, [c_i64, c_i32, c_i32]),
     "oasr_resample_poly": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp]),
@@ -126,6 +127,10 @@ def lib() -> C.CDLL:
                 raise OasrError(
                     f"{path} not found: build it with `make -C omnilingual-asr_amd/csrc` "
                     "(or __graft_entry__.build()); this package has no CPU fallback")
+            # torch first: it ships its own HIP runtime, and the process must end up with one.  If this library
+            # pulled in the system's copy before torch loaded its own (a host-only call such as the FLAC decoder
+            # made before any engine exists), the engine created later would find no device.
+            import torch  # noqa: F401
             handle = C.CDLL(str(path))
             for name, (res, args) in _SIGNATURES.items():
                 fn = getattr(handle, name)

@@ -302,6 +302,31 @@ def read_flac(path) -> tuple[np.ndarray, int]:
     return x, int(rate.value)
 
 
+def read_flac_pcm16(path):
+    """(int16 [frames * channels] interleaved, channels, sample_rate) of a FLAC file with at most 16 bits per
+    sample (value = integer / 32768), else None.  The native decoder writes the 16-bit samples directly."""
+    import ctypes as C
+
+    from . import _hip
+    with open(path, "rb") as f:
+        head = f.read(4)
+    if head != b"fLaC" and head[:3] != b"ID3":
+        return None
+    data = Path(path).read_bytes()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    rate, channels, bits, total = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+    L = _hip.lib()
+    _hip.check(L.oasr_flac_info(buf.ctypes.data, buf.size, C.byref(rate), C.byref(channels), C.byref(bits),
+                                C.byref(total), None), "oasr_flac_info")
+    if bits.value > 16:
+        return None
+    out = np.empty((max(total.value, 1) * channels.value,), dtype=np.int16)
+    written = C.c_int64()
+    _hip.check(L.oasr_flac_decode16(buf.ctypes.data, buf.size, out.ctypes.data, max(total.value, 1), C.byref(written)),
+               "oasr_flac_decode16")
+    return out[: written.value * channels.value], int(channels.value), int(rate.value)
+
+
 def read_audio(path) -> tuple[np.ndarray, int]:
     """Decode by content: (float32 [frames, channels], sample_rate)."""
     with open(path, "rb") as f:

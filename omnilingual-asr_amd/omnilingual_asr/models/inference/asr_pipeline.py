@@ -380,6 +380,8 @@ class GeminiASRPipeline:
         `load_audio_16k`); the rate conversion runs on the device when the engine offers it."""
         if hasattr(self.engine, "pcm16_to_16k"):
             mapped = _audio.map_wav_pcm16(audio_path)      # 16-bit PCM WAV: the device takes the file's samples as they are
+            if mapped is None and Path(audio_path).suffix.lower() == ".flac":
+                mapped = _audio.read_flac_pcm16(audio_path)  # FLAC of at most 16 bits: decoded to the same form
             if mapped is not None:
                 samples, channels, rate = mapped
                 if channels == 1 and rate == SAMPLE_RATE:

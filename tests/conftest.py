@@ -5,7 +5,7 @@ from pathlib import Path
 import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
-for p in (str(ROOT), str(ROOT / "omnilingual-asr_amd")):
+for p in (str(ROOT), str(ROOT / "omnilingual-asr_amd"), str(ROOT / "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 

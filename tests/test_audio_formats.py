@@ -228,3 +228,49 @@ def test_flac_through_transcribe(golden_dir, tiny_engine):
     from omnilingual_asr import Pipeline
     segs = Pipeline(engine=tiny_engine).transcribe(str(golden_dir / "reference_upload.flac"))
     assert len(segs) == 1 and segs[0].start == 0.0 and segs[0].end == 312060 / 16000.0 and segs[0].text
+
+
+def test_flac_long_stream_decodes_the_same_on_any_number_of_threads(golden_dir, tmp_path, monkeypatch):
+    """A stream of several MiB (the reference upload's frames repeated with fresh frame numbers, CRCs
+    recomputed: tests/flac_tools.py) is decoded by byte-range workers whose ranges must chain; the samples are
+    the short file's, repeated, for every thread count - and for the 16-bit output form."""
+    import flac_tools as ft
+
+    src = golden_dir / "reference_upload.flac"
+    x, rate = audio.read_flac(src)
+    ints = np.round(x * 32768.0).astype(np.int32)
+    stream, want = ft.repeat_stream(src.read_bytes(), 14, ints)
+    assert len(stream) > 4 << 20
+    p = tmp_path / "long.flac"
+    p.write_bytes(stream)
+    for threads in ("1", "2", "3", "4", "7"):
+        monkeypatch.setenv("OASR_FLAC_THREADS", threads)
+        y, r = audio.read_flac(p)
+        assert r == rate and np.array_equal(np.round(y * 32768.0).astype(np.int32), want), threads
+        s16, ch, r16 = audio.read_flac_pcm16(p)
+        assert (ch, r16) == (1, rate) and np.array_equal(s16.astype(np.int32), want[:, 0]), threads
+    # damage in the middle of the stream is reported whatever the thread count (the ranges no longer chain,
+    # the in-order decode names the frame)
+    bad = bytearray(stream)
+    bad[len(bad) // 2] ^= 0x40
+    p.write_bytes(bytes(bad))
+    for threads in ("1", "4"):
+        monkeypatch.setenv("OASR_FLAC_THREADS", threads)
+        with pytest.raises(Exception):
+            audio.read_flac(p)
+
+
+def test_flac_pcm16_form_of_short_and_narrow_streams(tmp_path):
+    """8-bit streams come out scaled to 16 bits; 24-bit streams have no 16-bit form."""
+    rng = np.random.default_rng(3)
+    v = rng.integers(-128, 128, 300).astype(np.int64)
+    data, want = _flac(1, 8, 8000, [[v]], 0, [9], rice=4)
+    p = tmp_path / "eight.flac"
+    p.write_bytes(data)
+    s16, ch, rate = audio.read_flac_pcm16(p)
+    assert (ch, rate) == (1, 8000) and np.array_equal(s16.astype(np.int64), want[:, 0] * 256)
+    x, _ = audio.read_flac(p)
+    assert np.array_equal(s16.astype(np.float32) / 32768.0, x[:, 0])
+    data24, _ = _flac(1, 24, 48000, [[rng.integers(-(1 << 20), 1 << 20, 100).astype(np.int64)]], 0, [9], rice=14)
+    p.write_bytes(data24)
+    assert audio.read_flac_pcm16(p) is None

@@ -76,3 +76,18 @@ def test_gettysburg_fixture_through_the_device_decode(golden_dir):
     got = pipe._load_audio(path)
     want = audio.load_audio_16k(path, lambda mono, r: pipe.engine.resample_16k(mono, r).cpu().numpy())
     assert np.array_equal(got, want)
+
+
+def test_flac_upload_through_the_device_decode(golden_dir):
+    """The reference's .flac upload: 16-bit samples from the native decoder, kept int16 (it is mono at 16 kHz);
+    the pipeline's records equal those of the float samples."""
+    from omnilingual_asr import Pipeline, audio
+
+    pipe = Pipeline(model="GTINY").gemini
+    path = golden_dir / "reference_upload.flac"
+    kept = pipe._load_audio(path)
+    assert kept.dtype == np.int16
+    flt = audio.load_audio_16k(path)
+    bounds = np.array([[0, kept.shape[0]]])
+    a, b = pipe._encode_chunks(kept, bounds), pipe._encode_chunks(flt, bounds)
+    assert a[0].n_frames == b[0].n_frames and np.array_equal(a[0].tokens, b[0].tokens)

@@ -1,34 +1,60 @@
 #!/usr/bin/env python3
-"""What a caller of the public API sees: `Pipeline.transcribe_with_retry(path)` on a long 16 kHz mono WAV written
-to local disk (synthetic noise + tone), end to end - file read, decode, chunk plan, device path, CTC stage,
-segments - with the time spent in audio loading shown separately.  Usage: transcribe_e2e.py [hours [rate [channels]]]"""
-import sys, time, wave, tempfile, os
+"""What a caller of the public API sees: `Pipeline.transcribe_with_retry(path)` on a long file written to local
+disk, end to end - file read, decode, chunk plan, device path, CTC stage, segments - with the time spent in audio
+loading shown separately.
+Usage: transcribe_e2e.py [hours [rate [channels]]]   16-bit WAV of synthetic noise + tone
+       transcribe_e2e.py flac [repeats]               FLAC made of the reference upload's frames (tests/flac_tools.py)"""
+import os, sys, tempfile, time, wave
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "omnilingual-asr_amd"))
 import numpy as np
 from omnilingual_asr.models.inference.asr_pipeline import GeminiASRPipeline
 
-hours = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
-rate = int(sys.argv[2]) if len(sys.argv) > 2 else 16000
-channels = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-n = int(hours * 3600 * rate)
-rng = np.random.default_rng(0)
-t = np.arange(n, dtype=np.float32)
-pcm = (3000 * rng.standard_normal(n).astype(np.float32) + 6000 * np.sin(t * (2 * np.pi * 440 / rate))).astype(np.int16)
-path = os.path.join(tempfile.gettempdir(), "oasr_e2e.wav")
-with wave.open(path, "wb") as w:
-    w.setnchannels(channels); w.setsampwidth(2); w.setframerate(rate)
-    w.writeframes(pcm.tobytes() if channels == 1 else np.repeat(pcm, channels).tobytes())
-del pcm, t
+
+def write_wav(hours: float, rate: int, channels: int) -> str:
+    n = int(hours * 3600 * rate)
+    rng = np.random.default_rng(0)
+    t = np.arange(n, dtype=np.float32)
+    pcm = (3000 * rng.standard_normal(n).astype(np.float32) + 6000 * np.sin(t * (2 * np.pi * 440 / rate))).astype(np.int16)
+    path = os.path.join(tempfile.gettempdir(), "oasr_e2e.wav")
+    with wave.open(path, "wb") as w:
+        w.setnchannels(channels); w.setsampwidth(2); w.setframerate(rate)
+        w.writeframes(pcm.tobytes() if channels == 1 else np.repeat(pcm, channels).tobytes())
+    return path
+
+
+def write_flac(repeats: int):
+    sys.path.insert(0, str(ROOT / "tests"))
+    import flac_tools as ft
+    from omnilingual_asr import audio
+    src = ROOT / "tests" / "golden" / "reference_upload.flac"
+    x, rate = audio.read_flac(src)
+    stream, want = ft.repeat_stream(src.read_bytes(), repeats, np.round(x * 32768).astype(np.int32))
+    path = os.path.join(tempfile.gettempdir(), "oasr_e2e.flac")
+    with open(path, "wb") as f:
+        f.write(stream)
+    return path, want.shape[0] / rate / 3600.0
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "flac":
+    path, hours = write_flac(int(sys.argv[2]) if len(sys.argv) > 2 else 400)
+else:
+    hours = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
+    path = write_wav(hours, int(sys.argv[2]) if len(sys.argv) > 2 else 16000, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
+print("%s: %.1f MB" % (path, os.path.getsize(path) / 1e6))
 pipe = GeminiASRPipeline(model="G300")
 load_s = [0.0]
 orig = pipe._load_audio
+
+
 def timed_load(p):
     t0 = time.perf_counter()
     out = orig(p)
     load_s[0] += time.perf_counter() - t0
     return out
+
+
 pipe._load_audio = timed_load
 for rep in range(3):
     load_s[0] = 0.0
