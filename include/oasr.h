@@ -260,7 +260,7 @@ int oasr_gemm_bf16_ex(const uint16_t* a, const uint16_t* w, const float* bias, c
  * STREAMINFO (md5_16 may be NULL; a sample count missing from the header is found by decoding);
  * oasr_flac_decode writes interleaved samples, sign-extended to int32 at the stream's bit depth;
  * oasr_flac_decode16 (streams of at most 16 bits per sample) writes them as int16 scaled to 16 bits, i.e.
- * sample / 32768 is the value in [-1, 1) - the form oasr_pcm16_to_mono_f32 takes.
+ * sample / 32768 is the value in [-1, 1) - a form oasr_pcm_to_mono_f32 takes (sample_bytes 2, bits 16).
  * Frame header CRC-8 and frame CRC-16 are verified.  Streams of a fixed block size with a known sample
  * count are decoded by up to 16 host threads, each on a byte range (a thread starts at the first position
  * of its range where a whole frame decodes and checks, and the ranges must chain byte for byte and sample for
@@ -366,11 +366,14 @@ int oasr_resample_poly(const float* x, int64_t n_in, int64_t x_stride, int32_t b
                        const double* hp, int32_t up, int32_t down, int32_t taps, int32_t half,
                        float* y, int64_t n_out, int64_t y_stride, void* stream);
 
-/* Interleaved 16-bit PCM (as a WAV file holds it; the formats the reference accepts are listed at
- * ref:src/omnilingual_asr/models/inference/gemini_pipeline.py:106-118) -> mono float32 in [-1, 1) on the device:
- * out[f] = (sum over channels of pcm[f * channels + c]) / (32768 * channels), the integer sum exact, one rounding
- * from float64.  pcm int16 [frames * channels] (2-byte aligned), out float32 [frames]; channels in 1..64. */
-int oasr_pcm16_to_mono_f32(const int16_t* pcm, int64_t frames, int32_t channels, float* out, void* stream);
+/* Interleaved integer PCM as a WAV file holds it, or as the FLAC decoder writes it (the formats the reference
+ * accepts are listed at ref:src/omnilingual_asr/models/inference/gemini_pipeline.py:106-118), -> mono float32 in
+ * [-1, 1) on the device.  sample_bytes is the container: 1 = unsigned 8-bit, 2 / 4 = little-endian int16 / int32
+ * (buffer aligned to the container), 3 = packed little-endian 24-bit; a sample's value is the integer /
+ * 2^(bits - 1), rounded to float32, and out[f] is the mean of frame f's channels taken in float64 and rounded
+ * once - what the host readers compute.  pcm [frames * channels] samples, out float32 [frames]; channels 1..64. */
+int oasr_pcm_to_mono_f32(const void* pcm, int64_t frames, int32_t channels, int32_t sample_bytes, int32_t bits,
+                         float* out, void* stream);
 
 #ifdef __cplusplus
 }

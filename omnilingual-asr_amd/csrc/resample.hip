@@ -35,33 +35,55 @@ __global__ __launch_bounds__(256) void resample_poly_kernel(const float* __restr
     y[(int64_t)blockIdx.y * y_stride + n] = (float)acc;
 }
 
-// Interleaved 16-bit PCM -> mono float32 in [-1, 1): out[f] = (sum over channels of pcm[f][c]) / (32768 * channels).
-// The integer sum is exact and the quotient is rounded once, from float64 - the value the host path gets from
-// float32 samples averaged in float64.  A thread produces one frame; HBM-bound: 2 * channels bytes in, 4 out.
-__global__ __launch_bounds__(256) void pcm16_to_mono_kernel(const int16_t* __restrict__ pcm, int64_t frames,
-                                                            int channels, float* __restrict__ out) {
+// Interleaved integer PCM as a file holds it -> mono float32 in [-1, 1): a sample is the integer / 2^(bits - 1),
+// rounded to float32 (exact up to 24 bits), and a frame is the mean of its channels taken in float64 and rounded
+// once - the arithmetic of the host readers (float32 samples, channels averaged in float64).  BYTES is the
+// container: 1 = unsigned 8-bit (offset 128), 2 / 4 = little-endian int16 / int32 (the buffer is aligned to the
+// container), 3 = packed little-endian 24-bit.  A thread produces one frame; HBM-bound.
+template <int BYTES>
+__global__ __launch_bounds__(256) void pcm_to_mono_kernel(const uint8_t* __restrict__ pcm, int64_t frames, int channels,
+                                                          double inv_full_scale, float* __restrict__ out) {
     const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (f >= frames) return;
-    const int16_t* p = pcm + f * channels;
-    int sum = 0;
-    for (int c = 0; c < channels; ++c) sum += p[c];
-    out[f] = (float)((double)sum / (32768.0 * channels));
+    const uint8_t* p = pcm + f * channels * BYTES;
+    double sum = 0.0;
+    for (int c = 0; c < channels; ++c, p += BYTES) {
+        int v;
+        if (BYTES == 1) v = (int)p[0] - 128;
+        else if (BYTES == 2) v = *reinterpret_cast<const int16_t*>(p);
+        else if (BYTES == 3) v = (int)p[0] | ((int)p[1] << 8) | ((int)(int8_t)p[2] << 16);
+        else v = *reinterpret_cast<const int32_t*>(p);
+        sum += (double)(float)((double)v * inv_full_scale);
+    }
+    out[f] = (float)(sum / channels);
 }
 
 }  // namespace oasr
 
 using namespace oasr;
 
-extern "C" int oasr_pcm16_to_mono_f32(const int16_t* pcm, int64_t frames, int32_t channels, float* out, void* stream) {
-    OASR_REQUIRE(pcm && out, "pcm16_to_mono: null pointer");
-    OASR_REQUIRE(frames >= 0 && channels >= 1 && channels <= 64, "pcm16_to_mono: frames=%lld must be >= 0 and channels=%d in 1..64",
+extern "C" int oasr_pcm_to_mono_f32(const void* pcm, int64_t frames, int32_t channels, int32_t sample_bytes, int32_t bits,
+                                    float* out, void* stream) {
+    OASR_REQUIRE(pcm && out, "pcm_to_mono: null pointer");
+    OASR_REQUIRE(frames >= 0 && channels >= 1 && channels <= 64, "pcm_to_mono: frames=%lld must be >= 0 and channels=%d in 1..64",
                  (long long)frames, channels);
+    OASR_REQUIRE(sample_bytes >= 1 && sample_bytes <= 4 && bits >= 2 && bits <= 8 * sample_bytes,
+                 "pcm_to_mono: sample_bytes=%d must be 1..4 and bits=%d in 2..8*sample_bytes", sample_bytes, bits);
+    OASR_REQUIRE(((uintptr_t)pcm & (sample_bytes == 3 ? 0 : sample_bytes - 1)) == 0, "pcm_to_mono: buffer not aligned to its samples");
     if (frames == 0) return OASR_OK;
     const int64_t blocks = (frames + 255) / 256;
-    OASR_REQUIRE(blocks < ((int64_t)1 << 31), "pcm16_to_mono: too many frames per launch");
-    hipLaunchKernelGGL(pcm16_to_mono_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pcm, frames,
-                       channels, out);
-    OASR_CHECK_LAUNCH("pcm16_to_mono");
+    OASR_REQUIRE(blocks < ((int64_t)1 << 31), "pcm_to_mono: too many frames per launch");
+    const double inv = 1.0 / (double)((int64_t)1 << (bits - 1));
+    const uint8_t* src = static_cast<const uint8_t*>(pcm);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)blocks), blk(256);
+    switch (sample_bytes) {
+        case 1: hipLaunchKernelGGL(pcm_to_mono_kernel<1>, grid, blk, 0, st, src, frames, channels, inv, out); break;
+        case 2: hipLaunchKernelGGL(pcm_to_mono_kernel<2>, grid, blk, 0, st, src, frames, channels, inv, out); break;
+        case 3: hipLaunchKernelGGL(pcm_to_mono_kernel<3>, grid, blk, 0, st, src, frames, channels, inv, out); break;
+        default: hipLaunchKernelGGL(pcm_to_mono_kernel<4>, grid, blk, 0, st, src, frames, channels, inv, out); break;
+    }
+    OASR_CHECK_LAUNCH("pcm_to_mono");
     return OASR_OK;
 }
 

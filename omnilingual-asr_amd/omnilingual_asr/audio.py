@@ -79,10 +79,11 @@ def read_wav(path) -> tuple[np.ndarray, int]:
     return x.reshape(n, channels), int(rate)
 
 
-def map_wav_pcm16(path):
-    """(int16 [frames * channels] interleaved view of the memory-mapped file, channels, sample_rate) when `path`
-    is a 16-bit PCM WAV, else None.  A sample's value in [-1, 1) is the integer / 32768; nothing is read,
-    converted or copied here: the pages are touched when the samples are used."""
+def map_wav_pcm(path):
+    """(uint8 view of the memory-mapped file's sample bytes, channels, sample_rate, bytes per sample, bits) when
+    `path` is an integer PCM WAV of 8, 16, 24 or 32 bits, else None.  Samples are interleaved, little-endian
+    (8-bit: unsigned); a sample's value in [-1, 1) is the integer / 2^(bits - 1).  Nothing is read, converted
+    or copied here: the pages are touched when the samples are used."""
     import mmap
     with open(path, "rb") as f:
         size = f.seek(0, 2)
@@ -106,10 +107,19 @@ def map_wav_pcm16(path):
     tag, channels, rate, _, block, bits = struct.unpack_from("<HHIIHH", fmt, 0)
     if tag == 0xFFFE and len(fmt) >= 26:
         tag = struct.unpack_from("<H", fmt, 24)[0]
-    if tag != 1 or bits != 16 or channels < 1 or channels > 64 or block != 2 * channels or rate < 1:
+    if tag != 1 or bits not in (8, 16, 24, 32) or channels < 1 or channels > 64 or block != bits // 8 * channels or rate < 1:
         return None
     frames = data_len // block
-    return np.frombuffer(mm, dtype="<i2", count=frames * channels, offset=data_at), int(channels), int(rate)
+    return np.frombuffer(mm, dtype=np.uint8, count=frames * block, offset=data_at), int(channels), int(rate), bits // 8, int(bits)
+
+
+def map_wav_pcm16(path):
+    """(int16 [frames * channels] interleaved view of the memory-mapped file, channels, sample_rate) when `path`
+    is a 16-bit PCM WAV (see `map_wav_pcm`), else None."""
+    m = map_wav_pcm(path)
+    if m is None or m[3] != 2:
+        return None
+    return m[0].view("<i2"), m[1], m[2]
 
 
 def read_wav_pcm16_mono(path):
@@ -302,9 +312,10 @@ def read_flac(path) -> tuple[np.ndarray, int]:
     return x, int(rate.value)
 
 
-def read_flac_pcm16(path):
-    """(int16 [frames * channels] interleaved, channels, sample_rate) of a FLAC file with at most 16 bits per
-    sample (value = integer / 32768), else None.  The native decoder writes the 16-bit samples directly."""
+def read_flac_pcm(path):
+    """(interleaved integer samples, channels, sample_rate, bytes per sample, bits) of a FLAC file, or None when
+    it is not one: int16 scaled to 16 bits for streams of at most 16 bits per sample (bits = 16), else int32 at
+    the stream's depth.  A sample's value in [-1, 1) is the integer / 2^(bits - 1)."""
     import ctypes as C
 
     from . import _hip
@@ -318,13 +329,33 @@ def read_flac_pcm16(path):
     L = _hip.lib()
     _hip.check(L.oasr_flac_info(buf.ctypes.data, buf.size, C.byref(rate), C.byref(channels), C.byref(bits),
                                 C.byref(total), None), "oasr_flac_info")
+    narrow = bits.value <= 16
+    out = np.empty((max(total.value, 1) * channels.value,), dtype=np.int16 if narrow else np.int32)
+    written = C.c_int64()
+    fn, what = (L.oasr_flac_decode16, "oasr_flac_decode16") if narrow else (L.oasr_flac_decode, "oasr_flac_decode")
+    _hip.check(fn(buf.ctypes.data, buf.size, out.ctypes.data, max(total.value, 1), C.byref(written)), what)
+    return (out[: written.value * channels.value], int(channels.value), int(rate.value),
+            2 if narrow else 4, 16 if narrow else int(bits.value))
+
+
+def read_flac_pcm16(path):
+    """(int16 interleaved, channels, sample_rate) of a FLAC file with at most 16 bits per sample, else None."""
+    with open(path, "rb") as f:
+        head = f.read(4)
+    if head != b"fLaC" and head[:3] != b"ID3":
+        return None
+    import ctypes as C
+
+    from . import _hip
+    data = Path(path).read_bytes()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    rate, channels, bits, total = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+    _hip.check(_hip.lib().oasr_flac_info(buf.ctypes.data, buf.size, C.byref(rate), C.byref(channels), C.byref(bits),
+                                         C.byref(total), None), "oasr_flac_info")
     if bits.value > 16:
         return None
-    out = np.empty((max(total.value, 1) * channels.value,), dtype=np.int16)
-    written = C.c_int64()
-    _hip.check(L.oasr_flac_decode16(buf.ctypes.data, buf.size, out.ctypes.data, max(total.value, 1), C.byref(written)),
-               "oasr_flac_decode16")
-    return out[: written.value * channels.value], int(channels.value), int(rate.value)
+    m = read_flac_pcm(path)
+    return m[0], m[1], m[2]
 
 
 def read_audio(path) -> tuple[np.ndarray, int]:

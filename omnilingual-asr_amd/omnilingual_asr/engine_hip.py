@@ -49,7 +49,7 @@ class HipEngine:
         self._tickets: dict = {}
         self._copy_stream = None
         self.use_graphs = use_graphs
-        self._pcm16_stage = None
+        self._pcm_stage = None
         self.max_buffer_sets = 6        # distinct (batch, padded length) shapes kept resident
 
     # ---- set-up ---------------------------------------------------------------------------------------
@@ -228,36 +228,39 @@ class HipEngine:
                        "oasr_resample_poly")
         return y[0] if squeeze else y
 
-    def pcm16_to_16k(self, interleaved: np.ndarray, channels: int, rate_in: int) -> np.ndarray:
-        """Interleaved int16 samples as a WAV file holds them (e.g. a memory-mapped file) -> mono float32 at
-        16 kHz on the host.  The file's bytes go to the device through two page-locked staging blocks, the
-        down-mix / conversion and the rate conversion run there, and only the 16 kHz signal comes back - the
-        host never holds a float copy of the file at its own rate.  Equal, bit for bit, to decoding on the
-        host (float32 samples, channels averaged in float64) followed by `resample_16k`."""
-        x = np.asarray(interleaved)
-        if x.dtype != np.int16 or x.ndim != 1 or channels < 1 or x.shape[0] % channels:
-            raise ValueError("pcm16_to_16k wants a flat int16 array of frames * channels samples")
-        total, frames = int(x.shape[0]), int(x.shape[0]) // int(channels)
+    def pcm_to_16k(self, samples: np.ndarray, channels: int, rate_in: int, sample_bytes: int = 2, bits: int = 16) -> np.ndarray:
+        """Interleaved integer samples as a WAV file holds them (e.g. a memory-mapped file) or as the FLAC decoder
+        writes them -> mono float32 at 16 kHz on the host.  `samples`: any contiguous array over the sample bytes;
+        `sample_bytes` 1 (unsigned 8-bit), 2, 3 (packed 24-bit) or 4, value = integer / 2^(bits - 1).  The bytes go
+        to the device through two page-locked staging blocks, the conversion, down-mix and rate conversion run
+        there, and only the 16 kHz signal comes back - the host never holds a float copy of the file at its own
+        rate.  Equal, bit for bit, to decoding on the host (float32 samples, channels averaged in float64)
+        followed by `resample_16k`."""
+        raw = np.ascontiguousarray(samples).reshape(-1).view(np.uint8)
+        frame_bytes = int(channels) * int(sample_bytes)
+        if channels < 1 or sample_bytes not in (1, 2, 3, 4) or raw.shape[0] % frame_bytes:
+            raise ValueError("pcm_to_16k wants whole frames of channels * sample_bytes bytes")
+        total, frames = int(raw.shape[0]), int(raw.shape[0]) // frame_bytes
         if frames == 0:
             return np.zeros((0,), dtype=np.float32)
-        block = 1 << 25                                                  # 64 MiB of samples per staging block
+        block = 12 << 22                                                 # 48 MiB: a whole number of samples of any width
         with torch.cuda.device(self.device):
-            raw = torch.empty((total,), dtype=torch.int16, device=self.device)
-            if self._pcm16_stage is None:
-                self._pcm16_stage = [torch.empty((block,), dtype=torch.int16).pin_memory() for _ in range(2)]
+            dev = torch.empty((total,), dtype=torch.uint8, device=self.device)
+            if self._pcm_stage is None:
+                self._pcm_stage = [torch.empty((block,), dtype=torch.uint8).pin_memory() for _ in range(2)]
             events = [torch.cuda.Event(), torch.cuda.Event()]
             for i, off in enumerate(range(0, total, block)):
                 n = min(block, total - off)
-                stage = self._pcm16_stage[i & 1]
+                stage = self._pcm_stage[i & 1]
                 if i >= 2:
                     events[i & 1].synchronize()                          # the block's previous copy has left it
-                stage.numpy()[:n] = x[off: off + n]
-                raw[off: off + n].copy_(stage[:n], non_blocking=True)
+                stage.numpy()[:n] = raw[off: off + n]
+                dev[off: off + n].copy_(stage[:n], non_blocking=True)
                 events[i & 1].record()
             mono = torch.empty((frames,), dtype=torch.float32, device=self.device)
-            _hip.check(_hip.lib().oasr_pcm16_to_mono_f32(raw.data_ptr(), frames, int(channels), mono.data_ptr(),
-                                                         _hip.current_stream_ptr()), "oasr_pcm16_to_mono_f32")
-            del raw
+            _hip.check(_hip.lib().oasr_pcm_to_mono_f32(dev.data_ptr(), frames, int(channels), int(sample_bytes), int(bits),
+                                                       mono.data_ptr(), _hip.current_stream_ptr()), "oasr_pcm_to_mono_f32")
+            del dev
             return self.resample_16k(mono, rate_in).cpu().numpy()
 
     def decode(self, hidden: torch.Tensor, lengths: torch.Tensor, buf=None):

@@ -378,16 +378,16 @@ class GeminiASRPipeline:
     def _load_audio(self, audio_path) -> np.ndarray:
         """Mono float32 at 16 kHz (int16 samples, value / 32768, for a mono 16-bit WAV already at 16 kHz: see
         `load_audio_16k`); the rate conversion runs on the device when the engine offers it."""
-        if hasattr(self.engine, "pcm16_to_16k"):
-            mapped = _audio.map_wav_pcm16(audio_path)      # 16-bit PCM WAV: the device takes the file's samples as they are
+        if hasattr(self.engine, "pcm_to_16k"):
+            mapped = _audio.map_wav_pcm(audio_path)        # integer PCM WAV: the device takes the file's samples as they are
             if mapped is None and Path(audio_path).suffix.lower() == ".flac":
-                mapped = _audio.read_flac_pcm16(audio_path)  # FLAC of at most 16 bits: decoded to the same form
+                mapped = _audio.read_flac_pcm(audio_path)  # FLAC: decoded to the same form by the native decoder
             if mapped is not None:
-                samples, channels, rate = mapped
-                if channels == 1 and rate == SAMPLE_RATE:
-                    return samples
+                samples, channels, rate, sample_bytes, bits = mapped
+                if channels == 1 and rate == SAMPLE_RATE and sample_bytes == 2 and bits == 16:
+                    return samples.view("<i2") if samples.dtype == np.uint8 else samples
                 with self._engine_lock:
-                    return self.engine.pcm16_to_16k(samples, channels, rate)
+                    return self.engine.pcm_to_16k(samples, channels, rate, sample_bytes, bits)
         resampler = None
         if hasattr(self.engine, "resample_16k"):
             def resampler(mono, rate):

@@ -48,24 +48,53 @@ def test_pipeline_uses_device_resampler(golden_dir):
     np.testing.assert_allclose(got, ref, rtol=0, atol=1.2e-7)
 
 
-@pytest.mark.parametrize("channels,rate", [(2, 48000), (1, 44100), (2, 16000), (3, 22050)])
-def test_pcm16_files_decoded_on_the_device_equal_the_host_decode(tmp_path, channels, rate):
-    """16-bit WAVs go to the device as the file holds them (down-mix, conversion and rate conversion there);
-    the 16 kHz signal equals host decoding + the same device resampler bit for bit."""
-    import wave
+@pytest.mark.parametrize("channels,rate,width", [(2, 48000, 2), (1, 44100, 2), (2, 16000, 2), (3, 22050, 2),
+                                                 (2, 48000, 3), (1, 16000, 3), (2, 44100, 4), (1, 8000, 1), (2, 11025, 1)])
+def test_pcm_files_decoded_on_the_device_equal_the_host_decode(tmp_path, channels, rate, width):
+    """Integer PCM WAVs (8, 16, 24, 32 bits) go to the device as the file holds them (conversion, down-mix and
+    rate conversion there); the 16 kHz signal equals host decoding + the same device resampler bit for bit."""
+    import struct
     from omnilingual_asr import Pipeline, audio
 
-    rng = np.random.default_rng(11)
+    rng = np.random.default_rng(11 + width)
     frames = int(rate * 2.37)
-    pcm = rng.integers(-32768, 32768, size=frames * channels, dtype=np.int16)
+    n = frames * channels
+    if width == 1:
+        payload = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+    elif width == 2:
+        payload = rng.integers(-32768, 32768, size=n, dtype=np.int16).tobytes()
+    elif width == 3:
+        v = rng.integers(-(1 << 23), 1 << 23, size=n, dtype=np.int32)
+        payload = v.astype("<i4").view(np.uint8).reshape(-1, 4)[:, :3].tobytes()
+    else:
+        payload = rng.integers(-(1 << 31), 1 << 31, size=n, dtype=np.int64).astype("<i4").tobytes()
+    fmt = struct.pack("<HHIIHH", 1, channels, rate, rate * channels * width, channels * width, 8 * width)
     path = tmp_path / "x.wav"
-    with wave.open(str(path), "wb") as w:
-        w.setnchannels(channels); w.setsampwidth(2); w.setframerate(rate); w.writeframes(pcm.tobytes())
+    path.write_bytes(b"RIFF" + struct.pack("<I", 36 + len(payload)) + b"WAVEfmt " + struct.pack("<I", 16) + fmt +
+                     b"data" + struct.pack("<I", len(payload)) + payload)
     pipe = Pipeline(model="GTINY").gemini
     got = pipe._load_audio(path)
     want = audio.load_audio_16k(path, lambda mono, r: pipe.engine.resample_16k(mono, r).cpu().numpy())
+    if got.dtype == np.int16:           # mono 16-bit at 16 kHz stays as read
+        got = got.astype(np.float32) / 32768.0
     assert got.dtype == np.float32 and got.shape == want.shape
     assert np.array_equal(got, want)
+
+
+def test_24_bit_flac_decoded_on_the_device_equals_the_host_decode(tmp_path):
+    from test_audio_formats import _flac
+    from omnilingual_asr import Pipeline, audio
+
+    rng = np.random.default_rng(2)
+    l = rng.integers(-(1 << 22), 1 << 22, 700).astype(np.int64)
+    r = (l // 3 + rng.integers(-1000, 1000, 700)).astype(np.int64)
+    data, _ = _flac(2, 24, 48000, [[l[:400], r[:400]], [l[400:], r[400:]]], 10, [10], rice=14)
+    path = tmp_path / "deep.flac"
+    path.write_bytes(data)
+    pipe = Pipeline(model="GTINY").gemini
+    got = pipe._load_audio(path)
+    want = audio.load_audio_16k(path, lambda mono, rr: pipe.engine.resample_16k(mono, rr).cpu().numpy())
+    assert got.dtype == np.float32 and np.array_equal(got, want)
 
 
 def test_gettysburg_fixture_through_the_device_decode(golden_dir):

@@ -2,7 +2,7 @@
 """What a caller of the public API sees: `Pipeline.transcribe_with_retry(path)` on a long file written to local
 disk, end to end - file read, decode, chunk plan, device path, CTC stage, segments - with the time spent in audio
 loading shown separately.
-Usage: transcribe_e2e.py [hours [rate [channels]]]   16-bit WAV of synthetic noise + tone
+Usage: transcribe_e2e.py [hours [rate [channels [width]]]]   WAV of synthetic noise + tone (width 2 or 3 bytes)
        transcribe_e2e.py flac [repeats]               FLAC made of the reference upload's frames (tests/flac_tools.py)"""
 import os, sys, tempfile, time, wave
 from pathlib import Path
@@ -12,15 +12,21 @@ import numpy as np
 from omnilingual_asr.models.inference.asr_pipeline import GeminiASRPipeline
 
 
-def write_wav(hours: float, rate: int, channels: int) -> str:
+def write_wav(hours: float, rate: int, channels: int, width: int = 2) -> str:
     n = int(hours * 3600 * rate)
     rng = np.random.default_rng(0)
     t = np.arange(n, dtype=np.float32)
     pcm = (3000 * rng.standard_normal(n).astype(np.float32) + 6000 * np.sin(t * (2 * np.pi * 440 / rate))).astype(np.int16)
     path = os.path.join(tempfile.gettempdir(), "oasr_e2e.wav")
     with wave.open(path, "wb") as w:
-        w.setnchannels(channels); w.setsampwidth(2); w.setframerate(rate)
-        w.writeframes(pcm.tobytes() if channels == 1 else np.repeat(pcm, channels).tobytes())
+        w.setnchannels(channels); w.setsampwidth(width); w.setframerate(rate)
+        pcm = pcm if channels == 1 else np.repeat(pcm, channels)
+        if width == 3:      # 24-bit: the 16-bit signal in the upper bytes
+            b = np.zeros((pcm.shape[0], 3), dtype=np.uint8)
+            b[:, 1:] = pcm.astype("<i2").view(np.uint8).reshape(-1, 2)
+            w.writeframes(b.tobytes())
+        else:
+            w.writeframes(pcm.tobytes())
     return path
 
 
@@ -41,7 +47,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "flac":
     path, hours = write_flac(int(sys.argv[2]) if len(sys.argv) > 2 else 400)
 else:
     hours = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
-    path = write_wav(hours, int(sys.argv[2]) if len(sys.argv) > 2 else 16000, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
+    path = write_wav(hours, int(sys.argv[2]) if len(sys.argv) > 2 else 16000, int(sys.argv[3]) if len(sys.argv) > 3 else 1,
+                     int(sys.argv[4]) if len(sys.argv) > 4 else 2)
 print("%s: %.1f MB" % (path, os.path.getsize(path) / 1e6))
 pipe = GeminiASRPipeline(model="G300")
 load_s = [0.0]
