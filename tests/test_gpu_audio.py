@@ -120,3 +120,25 @@ def test_flac_upload_through_the_device_decode(golden_dir):
     bounds = np.array([[0, kept.shape[0]]])
     a, b = pipe._encode_chunks(kept, bounds), pipe._encode_chunks(flt, bounds)
     assert a[0].n_frames == b[0].n_frames and np.array_equal(a[0].tokens, b[0].tokens)
+
+
+def test_host_only_call_before_the_engine_leaves_the_device_usable(golden_dir):
+    """A host-only entry point (the FLAC decoder) used before any engine exists must not leave the process
+    with a second HIP runtime: the library loader brings torch's in first.  Run in a child process, where
+    nothing has touched torch or the library yet."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from omnilingual_asr import audio\n"
+        "x, r = audio.read_flac(%r)\n"
+        "from omnilingual_asr import Pipeline\n"
+        "segs = Pipeline(model='GTINY').transcribe(%r)\n"
+        "print('segments', len(segs), r)\n"
+    ) % (str(root / "omnilingual-asr_amd"), str(golden_dir / "reference_upload.flac"), str(golden_dir / "reference_upload.flac"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=110)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "segments 1 16000" in out.stdout
