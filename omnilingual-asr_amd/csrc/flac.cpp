@@ -476,9 +476,15 @@ static int64_t decode_parallel(const uint8_t* d, size_t n, const StreamInfo& si,
         pt.ok = true;
     };
     std::vector<std::thread> pool;
-    for (int k = 1; k < threads; ++k) pool.emplace_back(work, k);
-    work(0);
+    bool started = true;
+    try {
+        for (int k = 1; k < threads; ++k) pool.emplace_back(work, k);
+    } catch (...) {   // no more threads to be had: finish what started, then decode in order
+        started = false;
+    }
+    if (started) work(0);
     for (auto& t : pool) t.join();
+    if (!started) return -1;
     // chain check
     size_t at = begin;
     int64_t s_at = 0;
