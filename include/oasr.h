@@ -375,6 +375,14 @@ int oasr_resample_poly(const float* x, int64_t n_in, int64_t x_stride, int32_t b
 int oasr_pcm_to_mono_f32(const void* pcm, int64_t frames, int32_t channels, int32_t sample_bytes, int32_t bits,
                          float* out, void* stream);
 
+/* Batch assembly on the device, for a signal that is already there (a file converted by oasr_pcm_to_mono_f32 and
+ * oasr_resample_poly): out[i][0 .. width) = pcm[start[i] .. start[i] + len[i]) followed by zeros - what the
+ * reference's chunk loop does with file slices (ref gemini_pipeline.py:243-310), without the samples visiting the
+ * host.  start int64 [batch] and len int32 [batch] are device arrays; the caller guarantees 0 <= start[i],
+ * start[i] + len[i] <= pcm_len and len[i] <= width. */
+int oasr_gather_chunks(const float* pcm, int64_t pcm_len, const int64_t* start, const int32_t* len, int32_t batch,
+                       int64_t width, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,9 +58,40 @@ __global__ __launch_bounds__(256) void pcm_to_mono_kernel(const uint8_t* __restr
     out[f] = (float)(sum / channels);
 }
 
+// Batch assembly on the device: row i of `out` = pcm[start[i] .. start[i] + len[i]) followed by zeros up to `width`.
+// Work-group (x, i) handles 1024 consecutive samples of row i, four per thread; HBM-bound: 4 bytes in, 4 out.
+__global__ __launch_bounds__(256) void gather_chunks_kernel(const float* __restrict__ pcm, const int64_t* __restrict__ start,
+                                                            const int32_t* __restrict__ len, int64_t width,
+                                                            float* __restrict__ out) {
+    const int i = blockIdx.y;
+    const int64_t s0 = start[i];
+    const int n = len[i];
+    float* row = out + (int64_t)i * width;
+    const int64_t j0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t j = j0 + u;
+        if (j < width) row[j] = j < n ? pcm[s0 + j] : 0.0f;
+    }
+}
+
 }  // namespace oasr
 
 using namespace oasr;
+
+extern "C" int oasr_gather_chunks(const float* pcm, int64_t pcm_len, const int64_t* start, const int32_t* len,
+                                  int32_t batch, int64_t width, float* out, void* stream) {
+    OASR_REQUIRE(pcm && start && len && out, "gather_chunks: null pointer");
+    OASR_REQUIRE(batch > 0 && batch <= 65535 && width > 0 && pcm_len >= 0, "gather_chunks: bad batch, width or signal length");
+    const int64_t blocks = (width + 1023) / 1024;
+    OASR_REQUIRE(blocks < ((int64_t)1 << 31), "gather_chunks: rows too wide");
+    // start / len are device arrays: their range (0 <= start, start + len <= pcm_len, len <= width) is the caller's
+    // to guarantee - the host pipeline checks its plan before it uploads them
+    hipLaunchKernelGGL(gather_chunks_kernel, dim3((unsigned)blocks, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, pcm,
+                       start, len, width, out);
+    OASR_CHECK_LAUNCH("gather_chunks");
+    return OASR_OK;
+}
 
 extern "C" int oasr_pcm_to_mono_f32(const void* pcm, int64_t frames, int32_t channels, int32_t sample_bytes, int32_t bits,
                                     float* out, void* stream) {

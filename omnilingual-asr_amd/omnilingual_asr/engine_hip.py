@@ -50,6 +50,7 @@ class HipEngine:
         self._copy_stream = None
         self.use_graphs = use_graphs
         self._pcm_stage = None
+        self._copy_pool = None
         self.max_buffer_sets = 6        # distinct (batch, padded length) shapes kept resident
 
     # ---- set-up ---------------------------------------------------------------------------------------
@@ -228,14 +229,16 @@ class HipEngine:
                        "oasr_resample_poly")
         return y[0] if squeeze else y
 
-    def pcm_to_16k(self, samples: np.ndarray, channels: int, rate_in: int, sample_bytes: int = 2, bits: int = 16) -> np.ndarray:
+    def pcm_to_16k(self, samples: np.ndarray, channels: int, rate_in: int, sample_bytes: int = 2, bits: int = 16,
+                   on_device: bool = False):
         """Interleaved integer samples as a WAV file holds them (e.g. a memory-mapped file) or as the FLAC decoder
         writes them -> mono float32 at 16 kHz on the host.  `samples`: any contiguous array over the sample bytes;
         `sample_bytes` 1 (unsigned 8-bit), 2, 3 (packed 24-bit) or 4, value = integer / 2^(bits - 1).  The bytes go
         to the device through two page-locked staging blocks, the conversion, down-mix and rate conversion run
         there, and only the 16 kHz signal comes back - the host never holds a float copy of the file at its own
         rate.  Equal, bit for bit, to decoding on the host (float32 samples, channels averaged in float64)
-        followed by `resample_16k`."""
+        followed by `resample_16k`.  With `on_device` the 16 kHz signal stays where it is (a float32 device
+        tensor): `submit(..., source=...)` assembles batches from it there."""
         raw = np.ascontiguousarray(samples).reshape(-1).view(np.uint8)
         frame_bytes = int(channels) * int(sample_bytes)
         if channels < 1 or sample_bytes not in (1, 2, 3, 4) or raw.shape[0] % frame_bytes:
@@ -254,14 +257,32 @@ class HipEngine:
                 stage = self._pcm_stage[i & 1]
                 if i >= 2:
                     events[i & 1].synchronize()                          # the block's previous copy has left it
-                stage.numpy()[:n] = raw[off: off + n]
+                self._parallel_copy(stage.numpy(), raw, off, n)
                 dev[off: off + n].copy_(stage[:n], non_blocking=True)
                 events[i & 1].record()
             mono = torch.empty((frames,), dtype=torch.float32, device=self.device)
             _hip.check(_hip.lib().oasr_pcm_to_mono_f32(dev.data_ptr(), frames, int(channels), int(sample_bytes), int(bits),
                                                        mono.data_ptr(), _hip.current_stream_ptr()), "oasr_pcm_to_mono_f32")
             del dev
-            return self.resample_16k(mono, rate_in).cpu().numpy()
+            y = self.resample_16k(mono, rate_in)
+            return y if on_device else y.cpu().numpy()
+
+    def _parallel_copy(self, dst: np.ndarray, src: np.ndarray, off: int, n: int, parts: int = 4) -> None:
+        """dst[:n] = src[off : off + n] by a few threads (numpy releases the GIL while it copies): the source is a
+        memory-mapped file, and one thread's page faults and copy leave most of the host's bandwidth unused."""
+        if n < (8 << 20):
+            dst[:n] = src[off: off + n]
+            return
+        if self._copy_pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._copy_pool = ThreadPoolExecutor(max_workers=parts, thread_name_prefix="oasr-stage")
+        step = -(-n // parts)
+
+        def piece(i):
+            lo, hi = i * step, min(n, (i + 1) * step)
+            if hi > lo:
+                dst[lo:hi] = src[off + lo: off + hi]
+        list(self._copy_pool.map(piece, range(parts)))
 
     def decode(self, hidden: torch.Tensor, lengths: torch.Tensor, buf=None):
         """Encoder states float32 [B, t_pad, d] (as returned by `encode_features`) and lengths int32 [B]
@@ -442,9 +463,13 @@ class HipEngine:
                 t["busy"] = False
             return t, t["stage"].numpy()
 
-    def submit(self, ticket, n_valid) -> None:
-        """Queue the batch assembled in the ticket's array; returns without waiting for the device."""
+    def submit(self, ticket, n_valid, source=None) -> None:
+        """Queue the batch assembled in the ticket's array; returns without waiting for the device.
+        `source` = (signal, starts): the batch is instead gathered on the device from a float32 device tensor
+        (row i = signal[starts[i] : starts[i] + n_valid[i]], zeros after), and nothing is uploaded."""
         t = ticket
+        if source is not None:
+            return self._submit_from_device(t, n_valid, *source)
         with torch.cuda.device(self.device):
             if self._copy_stream is None:
                 self._copy_stream = torch.cuda.Stream(self.device)
@@ -456,6 +481,33 @@ class HipEngine:
                 t["nv_d"].copy_(t["nv_pin"], non_blocking=True)
                 t["copied"].record()
             main.wait_event(t["copied"])
+            hidden, lengths = self._run(t["pcm_d"], t["nv_d"])
+            tok, frm, cnt = self.decode(hidden, lengths)
+            for name, src in (("tokens", tok), ("frames", frm), ("counts", cnt), ("lengths", lengths)):
+                t[name].copy_(src, non_blocking=True)
+            t["done"].record()
+            t["busy"] = True
+
+    def _submit_from_device(self, t, n_valid, signal: torch.Tensor, starts) -> None:
+        b, width = t["stage"].shape
+        nv = self._checked_lengths(n_valid, b, width)
+        st = np.asarray(starts, dtype=np.int64).reshape(-1)
+        if signal.dtype != torch.float32 or signal.dim() != 1 or not signal.is_cuda or st.shape[0] != b:
+            raise ValueError("source must be (float32 1-D device tensor, one start per row)")
+        if st.size and (st.min() < 0 or int((st + nv).max()) > signal.shape[0]):
+            raise ValueError("chunk bounds lie outside the signal")
+        with torch.cuda.device(self.device):
+            # the slot's small arrays are reused: the previous batch of this slot (same stream) has long read them
+            t["nv_pin"].numpy()[:] = nv
+            if "starts_pin" not in t:
+                t["starts_pin"] = torch.zeros((b,), dtype=torch.int64).pin_memory()
+                t["starts_d"] = torch.zeros((b,), dtype=torch.int64, device=self.device)
+            t["starts_pin"].numpy()[:] = st
+            t["nv_d"].copy_(t["nv_pin"], non_blocking=True)
+            t["starts_d"].copy_(t["starts_pin"], non_blocking=True)
+            _hip.check(_hip.lib().oasr_gather_chunks(signal.data_ptr(), int(signal.shape[0]), t["starts_d"].data_ptr(),
+                                                     t["nv_d"].data_ptr(), b, width, t["pcm_d"].data_ptr(),
+                                                     _hip.current_stream_ptr()), "oasr_gather_chunks")
             hidden, lengths = self._run(t["pcm_d"], t["nv_d"])
             tok, frm, cnt = self.decode(hidden, lengths)
             for name, src in (("tokens", tok), ("frames", frm), ("counts", cnt), ("lengths", lengths)):

@@ -343,11 +343,12 @@ class GeminiASRPipeline:
                 if width < longest:
                     raise ValueError("batch width %d does not cover its longest chunk (%d samples)" % (width, longest))
                 n_valid = [int(e - s) for s, e in part]
+                on_device = pipelined and not isinstance(pcm, np.ndarray)   # a float32 device tensor (see _load_audio)
                 if pipelined:
                     ticket, batch = self.engine.host_batch_slot(len(part), width, k)
                 else:
                     ticket, batch = None, np.empty((len(part), width), dtype=np.float32)
-                for i, (s, e) in enumerate(part):
+                for i, (s, e) in enumerate(() if on_device else part):
                     if pcm.dtype == np.int16:      # 16-bit samples kept as read: scaled while copied
                         np.multiply(pcm[s:e], np.float32(1.0 / 32768.0), out=batch[i, : e - s])
                     else:
@@ -355,7 +356,10 @@ class GeminiASRPipeline:
                     batch[i, e - s:] = 0.0
                 job = None
                 try:
-                    if pipelined:
+                    if on_device:       # the signal never left the device: the batch is gathered there
+                        self.engine.submit(ticket, n_valid, source=(pcm, [int(s) for s, _ in part]))
+                        job = (lo, part, ticket)
+                    elif pipelined:
                         self.engine.submit(ticket, n_valid)
                         job = (lo, part, ticket)
                     else:
@@ -387,7 +391,9 @@ class GeminiASRPipeline:
                 if channels == 1 and rate == SAMPLE_RATE and sample_bytes == 2 and bits == 16:
                     return samples.view("<i2") if samples.dtype == np.uint8 else samples
                 with self._engine_lock:
-                    return self.engine.pcm_to_16k(samples, channels, rate, sample_bytes, bits)
+                    # the converted signal stays on the device when the chunk loop can gather batches there
+                    return self.engine.pcm_to_16k(samples, channels, rate, sample_bytes, bits,
+                                                  on_device=hasattr(self.engine, "submit"))
         resampler = None
         if hasattr(self.engine, "resample_16k"):
             def resampler(mono, rate):

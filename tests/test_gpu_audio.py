@@ -43,6 +43,7 @@ def test_pipeline_uses_device_resampler(golden_dir):
 
     pipe = Pipeline(model="GTINY", seed=4)
     got = pipe.gemini._load_audio(golden_dir / "gettysburg.wav")
+    got = got.cpu().numpy() if isinstance(got, torch.Tensor) else got     # left on the device for the chunk loop
     ref = audio.load_audio_16k(golden_dir / "gettysburg.wav")
     assert got.shape == ref.shape == (281233,)
     np.testing.assert_allclose(got, ref, rtol=0, atol=1.2e-7)
@@ -75,7 +76,10 @@ def test_pcm_files_decoded_on_the_device_equal_the_host_decode(tmp_path, channel
     pipe = Pipeline(model="GTINY").gemini
     got = pipe._load_audio(path)
     want = audio.load_audio_16k(path, lambda mono, r: pipe.engine.resample_16k(mono, r).cpu().numpy())
-    if got.dtype == np.int16:           # mono 16-bit at 16 kHz stays as read
+    if isinstance(got, torch.Tensor):   # converted on the device and left there for the chunk loop
+        assert got.is_cuda and got.dtype == torch.float32
+        got = got.cpu().numpy()
+    elif got.dtype == np.int16:         # mono 16-bit at 16 kHz stays as read
         got = got.astype(np.float32) / 32768.0
     assert got.dtype == np.float32 and got.shape == want.shape
     assert np.array_equal(got, want)
@@ -92,7 +96,7 @@ def test_24_bit_flac_decoded_on_the_device_equals_the_host_decode(tmp_path):
     path = tmp_path / "deep.flac"
     path.write_bytes(data)
     pipe = Pipeline(model="GTINY").gemini
-    got = pipe._load_audio(path)
+    got = pipe._load_audio(path).cpu().numpy()
     want = audio.load_audio_16k(path, lambda mono, rr: pipe.engine.resample_16k(mono, rr).cpu().numpy())
     assert got.dtype == np.float32 and np.array_equal(got, want)
 
@@ -102,7 +106,7 @@ def test_gettysburg_fixture_through_the_device_decode(golden_dir):
 
     pipe = Pipeline(model="GTINY").gemini
     path = golden_dir / "gettysburg.wav"
-    got = pipe._load_audio(path)
+    got = pipe._load_audio(path).cpu().numpy()
     want = audio.load_audio_16k(path, lambda mono, r: pipe.engine.resample_16k(mono, r).cpu().numpy())
     assert np.array_equal(got, want)
 
@@ -142,3 +146,35 @@ def test_host_only_call_before_the_engine_leaves_the_device_usable(golden_dir):
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=110)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "segments 1 16000" in out.stdout
+
+
+def test_batches_gathered_on_the_device_equal_batches_assembled_on_the_host(tmp_path):
+    """A 48 kHz stereo file stays on the device after conversion and its chunks are gathered there
+    (oasr_gather_chunks); the records equal those of the same samples taken through the host."""
+    import wave
+    from omnilingual_asr import Pipeline
+
+    rng = np.random.default_rng(21)
+    rate, seconds = 48000, 75.3
+    n = int(rate * seconds)
+    pcm = (3000 * rng.standard_normal(n) + 5000 * np.sin(np.arange(n) * 2 * np.pi * 220 / rate)).astype(np.int16)
+    path = tmp_path / "stereo48.wav"
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(rate); w.writeframes(np.repeat(pcm, 2).tobytes())
+    pipe = Pipeline(model="GTINY", batch_size=2).gemini
+    dev = pipe._load_audio(path)
+    assert isinstance(dev, torch.Tensor) and dev.is_cuda
+    host = dev.cpu().numpy()
+    total = host.shape[0]
+    bounds = np.array([[0, 480000], [480000, 960000], [960000, total]])
+    a, b = pipe._encode_chunks(dev, bounds), pipe._encode_chunks(host, bounds)
+    assert len(a) == len(b) == 3
+    for ra, rb in zip(a, b):
+        assert (ra.chunk_idx, ra.start_sample, ra.end_sample, ra.n_frames) == (rb.chunk_idx, rb.start_sample, rb.end_sample, rb.n_frames)
+        assert np.array_equal(ra.tokens, rb.tokens) and np.array_equal(ra.frames, rb.frames)
+    # and through the public call
+    segs = Pipeline(model="GTINY", batch_size=2).transcribe(str(path))
+    assert [s.start for s in segs] == [0.0, 30.0, 60.0]
+    with pytest.raises(ValueError):
+        t, _ = pipe.engine.host_batch_slot(1, 480000, 0)
+        pipe.engine.submit(t, [480000], source=(dev, [total - 10]))     # runs past the end of the signal
