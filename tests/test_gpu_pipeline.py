@@ -328,3 +328,17 @@ def test_http_shell_on_the_hip_engine(tmp_path, golden_dir):
     assert [x["file_name"] for x in results] == ["a/one.wav", "a/two.wav", "three.wav", "four.wav"]
     for x, ref in zip(results, (want, want_long, want, want_long)):
         assert [(s["start"], s["end"], s["text"]) for s in x["segments"]] == [(s.start, s.end, s.text) for s in ref]
+
+
+def test_soak_of_mixed_files_through_one_pipeline():
+    """Thirty files of random length, rate, width and channel count through one pipeline (graphs per shape bucket,
+    buffer eviction, device- and host-resident samples): every transcript equals an eager pipeline's on freshly
+    decoded host samples (tools/soak.py)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    out = subprocess.run([sys.executable, str(root / "tools" / "soak.py"), "30"], capture_output=True, text=True, timeout=110)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    assert "30 files, 0 mismatches" in out.stdout
