@@ -272,6 +272,23 @@ int oasr_flac_decode(const uint8_t* data, int64_t size, int32_t* out, int64_t ca
 int oasr_flac_decode16(const uint8_t* data, int64_t size, int16_t* out, int64_t capacity_per_channel,
                        int64_t* written_per_channel);
 
+/* MPEG audio Layer III (MP3) decode on the host: the format of both demo recordings the reference ships and the first
+ * upload type it lists (ref gemini_pipeline.py:106-118 MIME table, workflows/wav2elan_web/app.py:76-77; the reference
+ * forwards the bytes to its remote model and uses ffmpeg only to cut them, ref :273-285).  First and second standard
+ * and the 2.5 extension (8 - 48 kHz), mono / stereo / joint stereo, every block type; ID3v2 tags are stepped over, an
+ * Info / Xing frame is not audio, and the encoder delay and padding a LAME-style tag states (plus the decoder's 529
+ * samples) are trimmed as ffmpeg does.  oasr_mp3_info scans the frame headers only.  oasr_mp3_decode writes
+ * interleaved float32 samples, nominally in [-1, 1) (not clipped); `diagnostics` may be NULL, else 5 words:
+ * audio frames, bytes stepped over while searching for frames, granules whose spectrum ran past its stated length,
+ * frames or granules delivered as silence (damaged, or their bit reservoir missing), stuffing bits.  Streams of 4096
+ * frames or more are decoded by up to 16 host threads on frame ranges (each starts 12 frames early and discards those:
+ * the samples equal an in-order decode); OASR_MP3_THREADS in the environment overrides the count.
+ * Free-format streams and Layers I / II return OASR_EINVAL. */
+int oasr_mp3_info(const uint8_t* data, int64_t size, int32_t* sample_rate, int32_t* channels,
+                  int64_t* samples_per_channel);
+int oasr_mp3_decode(const uint8_t* data, int64_t size, float* out, int64_t capacity_per_channel,
+                    int64_t* written_per_channel, int64_t* diagnostics);
+
 /* LayerNorm (optionally followed by Swish) straight to e4m3 rows + per-row scale: byte-identical to
  * oasr_layernorm(out_bf16=1) followed by oasr_quant_fp8_rows, without the intermediate bf16 matrix.
  * oasr_layernorm2_fp8 is the same for oasr_layernorm2 (x is overwritten with its first LayerNorm). */

@@ -1,12 +1,12 @@
-"""Audio ingest: WAV, AIFF/AIFF-C and FLAC decode, down-mix and polyphase resampling to 16 kHz mono
+"""Audio ingest: WAV, AIFF/AIFF-C, FLAC and MP3 decode, down-mix and polyphase resampling to 16 kHz mono
 float32.
 
 The reference hands the encoded file to its remote model and uses ffprobe/ffmpeg only for duration
 and slicing (ref:src/omnilingual_asr/models/inference/gemini_pipeline.py:222-310).  Here the host
-decodes the audio itself: PCM containers in this module, FLAC by the native decoder in
-liboasr_hip.so (`oasr_flac_decode`).  The file type is taken from its first bytes, not its name.  The
-lossy formats the reference lists (:106-118: mp3, aac, ogg, m4a) need decoders this package does not
-contain and raise `UnsupportedAudioError`.
+decodes the audio itself: PCM containers in this module, FLAC and MPEG Layer III by the native decoders in
+liboasr_hip.so (`oasr_flac_decode`, `oasr_mp3_decode`).  The file type is taken from its first bytes, not its
+name.  The other lossy formats the reference lists (:106-118: aac, ogg, m4a) need decoders this package does
+not contain and raise `UnsupportedAudioError`.
 """
 
 from __future__ import annotations
@@ -42,7 +42,7 @@ def read_wav(path) -> tuple[np.ndarray, int]:
     data = path.read_bytes()
     if data[:4] != b"RIFF":
         raise UnsupportedAudioError(
-            f"cannot decode '{path.suffix}' audio: WAV, AIFF and FLAC input is supported")
+            f"cannot decode '{path.suffix}' audio: WAV, AIFF, FLAC and MP3 input is supported")
     fmt = payload = None
     for cid, body in _riff_chunks(data):
         if cid == b"fmt ":
@@ -151,8 +151,8 @@ def wav_duration(path) -> float:
 
 
 def audio_duration(path) -> float:
-    """Duration in seconds from the header alone, for every container `read_audio` decodes (WAV data
-    chunk, AIFF COMM chunk, FLAC STREAMINFO); raises on anything unreadable."""
+    """Duration in seconds without decoding, for every container `read_audio` decodes (WAV data chunk, AIFF
+    COMM chunk, FLAC STREAMINFO; MP3: its frame headers are counted); raises on anything unreadable."""
     with open(path, "rb") as f:
         head = f.read(1 << 16)
     if head[:4] == b"RIFF":
@@ -173,6 +173,9 @@ def audio_duration(path) -> float:
         rate, total = x >> 44, x & ((1 << 36) - 1)
         if rate > 0 and total > 0:
             return total / float(rate)
+    if _looks_like_mp3(head, path):
+        rate, _, total = mp3_info(path)
+        return total / float(rate)
     raise UnsupportedAudioError("no duration in the header")
 
 
@@ -358,6 +361,53 @@ def read_flac_pcm16(path):
     return m[0], m[1], m[2]
 
 
+def _looks_like_mp3(head: bytes, path) -> bool:
+    """An ID3v2 tag (unless the name says FLAC, which may carry one too) or an MPEG audio Layer III frame header."""
+    if head[:3] == b"ID3":
+        return Path(path).suffix.lower() != ".flac"
+    return (len(head) >= 4 and head[0] == 0xFF and head[1] & 0xE0 == 0xE0 and (head[1] >> 3) & 3 != 1
+            and (head[1] >> 1) & 3 == 1 and head[2] >> 4 not in (0, 15) and (head[2] >> 2) & 3 != 3)
+
+
+def mp3_info(path) -> tuple[int, int, int]:
+    """(sample_rate, channels, samples per channel after the encoder delay and padding are trimmed) of an MP3 file."""
+    import ctypes as C
+
+    from . import _hip
+    buf = np.fromfile(path, dtype=np.uint8)
+    rate, channels, total = C.c_int32(), C.c_int32(), C.c_int64()
+    try:
+        _hip.check(_hip.lib().oasr_mp3_info(buf.ctypes.data, buf.size, C.byref(rate), C.byref(channels),
+                                            C.byref(total)), "oasr_mp3_info")
+    except _hip.OasrError as e:
+        raise UnsupportedAudioError(str(e)) from e
+    return int(rate.value), int(channels.value), int(total.value)
+
+
+def read_mp3(path, diagnostics: bool = False):
+    """Decode an MPEG Layer III file with the native decoder -> (float32 [frames, channels], rate); the samples are
+    nominally in [-1, 1) and not clipped.  With `diagnostics` a third value: int64 [5] = audio frames, bytes stepped
+    over while searching for frames, granules whose spectrum overran, frames or granules delivered as silence,
+    stuffing bits."""
+    import ctypes as C
+
+    from . import _hip
+    buf = np.fromfile(path, dtype=np.uint8)
+    rate, channels, total = C.c_int32(), C.c_int32(), C.c_int64()
+    L = _hip.lib()
+    try:
+        _hip.check(L.oasr_mp3_info(buf.ctypes.data, buf.size, C.byref(rate), C.byref(channels), C.byref(total)),
+                   "oasr_mp3_info")
+        out = np.zeros((total.value, channels.value), dtype=np.float32)
+        written, diag = C.c_int64(), np.zeros(5, dtype=np.int64)
+        _hip.check(L.oasr_mp3_decode(buf.ctypes.data, buf.size, out.ctypes.data, total.value, C.byref(written),
+                                     diag.ctypes.data), "oasr_mp3_decode")
+    except _hip.OasrError as e:
+        raise UnsupportedAudioError(str(e)) from e
+    out = out[: written.value]
+    return (out, int(rate.value), diag) if diagnostics else (out, int(rate.value))
+
+
 def read_audio(path) -> tuple[np.ndarray, int]:
     """Decode by content: (float32 [frames, channels], sample_rate)."""
     with open(path, "rb") as f:
@@ -368,8 +418,10 @@ def read_audio(path) -> tuple[np.ndarray, int]:
         return read_aiff(path)
     if head[:4] == b"fLaC" or head[:3] == b"ID3" and Path(path).suffix.lower() == ".flac":
         return read_flac(path)
+    if _looks_like_mp3(head, path):
+        return read_mp3(path)
     raise UnsupportedAudioError(
-        f"cannot decode '{Path(path).suffix}' audio: WAV, AIFF and FLAC input is supported")
+        f"cannot decode '{Path(path).suffix}' audio: WAV, AIFF, FLAC and MP3 input is supported")
 
 
 def load_audio_16k(path, resampler=None, keep_int16: bool = False) -> np.ndarray:
