@@ -288,6 +288,10 @@ int oasr_mp3_info(const uint8_t* data, int64_t size, int32_t* sample_rate, int32
                   int64_t* samples_per_channel);
 int oasr_mp3_decode(const uint8_t* data, int64_t size, float* out, int64_t capacity_per_channel,
                     int64_t* written_per_channel, int64_t* diagnostics);
+/* The same decode delivered as one channel: a stereo stream's two channels are averaged (the sum formed in double
+ * and rounded to float32 once: what averaging the two-channel output in float64 gives); `out` holds `capacity` samples. */
+int oasr_mp3_decode_mono(const uint8_t* data, int64_t size, float* out, int64_t capacity, int64_t* written,
+                         int64_t* diagnostics);
 
 /* LayerNorm (optionally followed by Swish) straight to e4m3 rows + per-row scale: byte-identical to
  * oasr_layernorm(out_bf16=1) followed by oasr_quant_fp8_rows, without the intermediate bf16 matrix.

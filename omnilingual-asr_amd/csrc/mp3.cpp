@@ -745,9 +745,10 @@ static const int kWarmFrames = 12;
 
 // Frames [first, last) of the plan -> out (positions relative to the whole stream); returns samples written per channel.
 static void decode_range(const uint8_t* d, const StreamPlan& sp, int64_t first, int64_t last, float* out,
-                         int64_t capacity, int64_t* diag) {
+                         int64_t capacity, int64_t* diag, bool mono) {
     Decoder dec;
     const int nch = sp.frames.front().h.channels;
+    const int nout = mono ? 1 : nch;
     const int spf = sp.frames.front().h.samples();
     std::vector<float> pcm((size_t)spf * 2);
     const int64_t warm = first - kWarmFrames < 0 ? 0 : first - kWarmFrames;
@@ -762,12 +763,14 @@ static void decode_range(const uint8_t* d, const StreamPlan& sp, int64_t first, 
             dec.decode_frame(d + sp.frames[f].at, h, pcm.data());
         }
         if (f < first) continue;
+        if (mono && nch == 2)   // the mean of the two channels, formed in double and rounded once
+            for (int i = 0; i < spf; ++i) pcm[i] = (float)(((double)pcm[2 * i] + (double)pcm[2 * i + 1]) * 0.5);
         int64_t s0 = f * spf - sp.lead, n = spf, skip = 0;   // this frame covers output samples [s0, s0 + spf)
         if (s0 < 0) skip = -s0;
         if (s0 + n > sp.keep) n = sp.keep - s0;
         if (s0 + n > capacity) n = capacity - s0;
         if (n > skip)
-            memcpy(out + (size_t)(s0 + skip) * nch, pcm.data() + (size_t)skip * nch, sizeof(float) * (size_t)(n - skip) * nch);
+            memcpy(out + (size_t)(s0 + skip) * nout, pcm.data() + (size_t)skip * nout, sizeof(float) * (size_t)(n - skip) * nout);
     }
     for (int k = 0; k < 5; ++k) diag[k] = dec.diag[k];
 }
@@ -791,8 +794,10 @@ int oasr_mp3_info(const uint8_t* data, int64_t size, int32_t* sample_rate, int32
     return OASR_OK;
 }
 
-int oasr_mp3_decode(const uint8_t* data, int64_t size, float* out, int64_t capacity_per_channel,
-                    int64_t* written_per_channel, int64_t* diagnostics) {
+}  // extern "C"
+
+static int mp3_decode_to(const uint8_t* data, int64_t size, float* out, int64_t capacity_per_channel,
+                         int64_t* written_per_channel, int64_t* diagnostics, bool mono) {
     OASR_REQUIRE(data && size > 0 && out && written_per_channel, "mp3_decode: null pointer");
     OASR_REQUIRE(capacity_per_channel >= 0, "mp3_decode: negative capacity");
     mp3::StreamPlan sp;
@@ -818,7 +823,7 @@ int oasr_mp3_decode(const uint8_t* data, int64_t size, float* out, int64_t capac
     if (threads > nf) threads = (int)nf;
     std::vector<int64_t> diag((size_t)threads * 5, 0);
     if (threads == 1) {
-        mp3::decode_range(data, sp, 0, nf, out, capacity_per_channel, diag.data());
+        mp3::decode_range(data, sp, 0, nf, out, capacity_per_channel, diag.data(), mono);
     } else {
         std::vector<std::thread> pool;
         bool spawn_failed = false;
@@ -826,7 +831,7 @@ int oasr_mp3_decode(const uint8_t* data, int64_t size, float* out, int64_t capac
             const int64_t a = nf * t / threads, b = nf * (t + 1) / threads;
             try {
                 pool.emplace_back(mp3::decode_range, data, std::cref(sp), a, b, out, capacity_per_channel,
-                                  diag.data() + (size_t)t * 5);
+                                  diag.data() + (size_t)t * 5, mono);
             } catch (...) {
                 spawn_failed = true;
                 break;
@@ -836,7 +841,7 @@ int oasr_mp3_decode(const uint8_t* data, int64_t size, float* out, int64_t capac
         if (spawn_failed) {   // a thread could not be started: decode everything in order instead
             std::fill(diag.begin(), diag.end(), 0);
             threads = 1;
-            mp3::decode_range(data, sp, 0, nf, out, capacity_per_channel, diag.data());
+            mp3::decode_range(data, sp, 0, nf, out, capacity_per_channel, diag.data(), mono);
         }
     }
     *written_per_channel = sp.keep;
@@ -848,6 +853,18 @@ int oasr_mp3_decode(const uint8_t* data, int64_t size, float* out, int64_t capac
         diagnostics[1] = sp.skipped;
     }
     return OASR_OK;
+}
+
+extern "C" {
+
+int oasr_mp3_decode(const uint8_t* data, int64_t size, float* out, int64_t capacity_per_channel,
+                    int64_t* written_per_channel, int64_t* diagnostics) {
+    return mp3_decode_to(data, size, out, capacity_per_channel, written_per_channel, diagnostics, false);
+}
+
+int oasr_mp3_decode_mono(const uint8_t* data, int64_t size, float* out, int64_t capacity, int64_t* written,
+                         int64_t* diagnostics) {
+    return mp3_decode_to(data, size, out, capacity, written, diagnostics, true);
 }
 
 }  // extern "C"

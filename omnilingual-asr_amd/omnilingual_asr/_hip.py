@@ -106,6 +106,7 @@ _SIGNATURES = {
     "oasr_flac_decode16": (c_i32, [c_vp, c_i64, c_vp, c_i64, C.POINTER(c_i64)]),
     "oasr_mp3_info": (c_i32, [c_vp, c_i64, C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_i64)]),
     "oasr_mp3_decode": (c_i32, [c_vp, c_i64, c_vp, c_i64, C.POINTER(c_i64), c_vp]),
+    "oasr_mp3_decode_mono": (c_i32, [c_vp, c_i64, c_vp, c_i64, C.POINTER(c_i64), c_vp]),
     "oasr_gather_chunks": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_i64, c_vp, c_vp]),
     "oasr_pcm_to_mono_f32": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "oasr_resample_length": (c_i64, [c_i64, c_i32, c_i32]),

@@ -408,6 +408,32 @@ def read_mp3(path, diagnostics: bool = False):
     return (out, int(rate.value), diag) if diagnostics else (out, int(rate.value))
 
 
+def read_mp3_mono(path) -> tuple[np.ndarray, int]:
+    """(float32 [frames], rate): `read_mp3` with the channels averaged inside the decoder - the values
+    `read_mp3(path)[0].mean(axis=1, dtype=float64)` rounds to, without the two-channel array."""
+    import ctypes as C
+
+    from . import _hip
+    buf = np.fromfile(path, dtype=np.uint8)
+    rate, channels, total = C.c_int32(), C.c_int32(), C.c_int64()
+    L = _hip.lib()
+    try:
+        _hip.check(L.oasr_mp3_info(buf.ctypes.data, buf.size, C.byref(rate), C.byref(channels), C.byref(total)),
+                   "oasr_mp3_info")
+        out = np.zeros((total.value,), dtype=np.float32)
+        written = C.c_int64()
+        _hip.check(L.oasr_mp3_decode_mono(buf.ctypes.data, buf.size, out.ctypes.data, total.value, C.byref(written),
+                                          None), "oasr_mp3_decode_mono")
+    except _hip.OasrError as e:
+        raise UnsupportedAudioError(str(e)) from e
+    return out[: written.value], int(rate.value)
+
+
+def is_mp3(path) -> bool:
+    with open(path, "rb") as f:
+        return _looks_like_mp3(f.read(12), path)
+
+
 def read_audio(path) -> tuple[np.ndarray, int]:
     """Decode by content: (float32 [frames, channels], sample_rate)."""
     with open(path, "rb") as f:
@@ -436,8 +462,11 @@ def load_audio_16k(path, resampler=None, keep_int16: bool = False) -> np.ndarray
         fast = read_wav_pcm16_mono(path) if is_riff else None
         if fast is not None and fast[1] == TARGET_RATE:
             return fast[0]
-    x, rate = read_audio(path)
-    mono = x.mean(axis=1, dtype=np.float64) if x.shape[1] > 1 else x[:, 0]
+    if is_mp3(path):
+        mono, rate = read_mp3_mono(path)
+    else:
+        x, rate = read_audio(path)
+        mono = x.mean(axis=1, dtype=np.float64) if x.shape[1] > 1 else x[:, 0]
     if resampler is not None and rate != TARGET_RATE:
         return np.asarray(resampler(np.asarray(mono, dtype=np.float32), rate), dtype=np.float32)
     return resample_poly(mono, rate, TARGET_RATE)

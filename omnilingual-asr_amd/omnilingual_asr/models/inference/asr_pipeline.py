@@ -394,6 +394,10 @@ class GeminiASRPipeline:
                     # the converted signal stays on the device when the chunk loop can gather batches there
                     return self.engine.pcm_to_16k(samples, channels, rate, sample_bytes, bits,
                                                   on_device=hasattr(self.engine, "submit"))
+        if hasattr(self.engine, "resample_16k") and hasattr(self.engine, "submit") and _audio.is_mp3(audio_path):
+            mono, rate = _audio.read_mp3_mono(audio_path)          # host threads decode; the rate conversion runs on
+            with self._engine_lock:                                # the device and the 16 kHz signal stays there
+                return self.engine.resample_16k(mono, rate)
         resampler = None
         if hasattr(self.engine, "resample_16k"):
             def resampler(mono, rate):

@@ -126,6 +126,25 @@ def test_flac_upload_through_the_device_decode(golden_dir):
     assert a[0].n_frames == b[0].n_frames and np.array_equal(a[0].tokens, b[0].tokens)
 
 
+def test_mp3_demo_through_the_device_path(golden_dir):
+    """The reference's demo recording (first 40 s, 44.1 kHz joint stereo): host threads decode and down-mix, the rate
+    conversion runs on the device and the 16 kHz signal stays there; it equals host decoding + the same resampler
+    bit for bit, and the public call returns the two 30 s-plan segments with text."""
+    from omnilingual_asr import Pipeline, audio
+
+    pipe = Pipeline(model="GTINY", seed=4)
+    path = golden_dir / "reference_demo_40s.mp3"
+    got = pipe.gemini._load_audio(path)
+    assert isinstance(got, torch.Tensor) and got.is_cuda and got.dtype == torch.float32
+    x, rate = audio.read_mp3(path)
+    want = pipe.gemini.engine.resample_16k(x.mean(axis=1, dtype=np.float64).astype(np.float32), rate).cpu().numpy()
+    assert rate == 44100 and got.shape[0] == -(-x.shape[0] * 160 // 441) and np.array_equal(got.cpu().numpy(), want)
+    np.testing.assert_allclose(want, audio.load_audio_16k(path), rtol=0, atol=1.2e-7)    # the host resampler
+    segs = pipe.transcribe(str(path))
+    assert [s.start for s in segs] == [0.0, 30.0] and segs[0].end == 30.0 and all(s.text for s in segs)
+    assert segs[1].end == pytest.approx(got.shape[0] / 16000.0, abs=1e-6)
+
+
 def test_host_only_call_before_the_engine_leaves_the_device_usable(golden_dir):
     """A host-only entry point (the FLAC decoder) used before any engine exists must not leave the process
     with a second HIP runtime: the library loader brings torch's in first.  Run in a child process, where

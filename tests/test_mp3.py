@@ -80,6 +80,17 @@ def test_thread_count_does_not_change_a_sample(golden_dir, monkeypatch):
         assert np.array_equal(out["1"][0], out[th][0]) and list(out["1"][2]) == list(out[th][2])
 
 
+def test_mono_form_equals_the_float64_mean(golden_dir, monkeypatch):
+    x, rate = audio.read_mp3(golden_dir / "reference_demo_40s.mp3")
+    for th in ("1", "3"):
+        monkeypatch.setenv("OASR_MP3_THREADS", th)
+        m, r = audio.read_mp3_mono(golden_dir / "reference_demo_40s.mp3")
+        assert r == rate and np.array_equal(m, x.mean(axis=1, dtype=np.float64).astype(np.float32))
+    y = audio.load_audio_16k(golden_dir / "reference_demo_40s.mp3")
+    assert y.dtype == np.float32 and y.shape[0] == -(-x.shape[0] * 160 // 441)
+    assert np.array_equal(y, audio.resample_poly(x.mean(axis=1, dtype=np.float64).astype(np.float32), rate))
+
+
 # ---- round trips through the test encoder ----------------------------------------------------------------------------
 def _band_noise(rng, n, rate, lo_line, lines, ch=1, amp=0.25):
     """Noise confined to MDCT lines [lo_line, lo_line + lines) of a 576-line granule."""
