@@ -35,13 +35,14 @@ namespace mp3 {
 struct Book {
     const int16_t (*nodes)[2];
     int linbits;
+    int id;   // which of the 16 distinct trees (index of its first-level table)
 };
 static const Book kBooks[32] = {
-    {nullptr, 0},   {kMp3Book1, 0},  {kMp3Book2, 0},  {kMp3Book3, 0},   {nullptr, 0},    {kMp3Book5, 0},  {kMp3Book6, 0},
-    {kMp3Book7, 0}, {kMp3Book8, 0},  {kMp3Book9, 0},  {kMp3Book10, 0},  {kMp3Book11, 0}, {kMp3Book12, 0}, {kMp3Book13, 0},
-    {nullptr, 0},   {kMp3Book15, 0}, {kMp3Book16, 1}, {kMp3Book16, 2},  {kMp3Book16, 3}, {kMp3Book16, 4}, {kMp3Book16, 6},
-    {kMp3Book16, 8}, {kMp3Book16, 10}, {kMp3Book16, 13}, {kMp3Book24, 4}, {kMp3Book24, 5}, {kMp3Book24, 6}, {kMp3Book24, 7},
-    {kMp3Book24, 8}, {kMp3Book24, 9}, {kMp3Book24, 11}, {kMp3Book24, 13}};
+    {nullptr, 0, 0},   {kMp3Book1, 0, 1},  {kMp3Book2, 0, 2},  {kMp3Book3, 0, 3},   {nullptr, 0, 0},    {kMp3Book5, 0, 4},  {kMp3Book6, 0, 5},
+    {kMp3Book7, 0, 6}, {kMp3Book8, 0, 7},  {kMp3Book9, 0, 8},  {kMp3Book10, 0, 9},  {kMp3Book11, 0, 10}, {kMp3Book12, 0, 11}, {kMp3Book13, 0, 12},
+    {nullptr, 0, 0},   {kMp3Book15, 0, 13}, {kMp3Book16, 1, 14}, {kMp3Book16, 2, 14},  {kMp3Book16, 3, 14}, {kMp3Book16, 4, 14}, {kMp3Book16, 6, 14},
+    {kMp3Book16, 8, 14}, {kMp3Book16, 10, 14}, {kMp3Book16, 13, 14}, {kMp3Book24, 4, 15}, {kMp3Book24, 5, 15}, {kMp3Book24, 6, 15}, {kMp3Book24, 7, 15},
+    {kMp3Book24, 8, 15}, {kMp3Book24, 9, 15}, {kMp3Book24, 11, 15}, {kMp3Book24, 13, 15}};
 
 // scale factor band edges; row = sampling frequency index: 44.1, 48, 32 | 22.05, 24, 16 | 11.025, 12, 8 kHz
 static const int16_t kLongEdges[9][23] = {
@@ -88,9 +89,13 @@ static const int32_t kWindowBase[257] = {
 
 struct Tables {
     float pow43[8207];        // n^(4/3)
-    float imdct_long[4][36][18];   // window shape x output x coefficient, window folded in
-    float imdct_short[12][6];
-    float synth_cos[64][32];
+    float imdct_cos[18][18];       // rows 0..8: outputs 0..8, rows 9..17: outputs 18..26 (the other 18 follow by symmetry)
+    float long_window[4][36];
+    float imdct_short[12][6];      // window folded in
+    double lee[32];                // fast DCT: 1 / (2 cos((2k + 1) pi / 2N)) at [N/2 + k]
+    // first level of every code tree: the next 8 bits -> (leaf << 4 | code length) for codes of at most 8 bits,
+    // else -(node reached after 8 bits) - 1; [16] is the quadruple book
+    int16_t first[17][256];
     float window[512];        // the standard's D[n]
     float cs[8], ca[8];
     float pan[7][2];          // first-standard intensity ratios (left, right)
@@ -102,14 +107,29 @@ struct Tables {
                 double w = sin(pi / 36 * (i + 0.5));
                 if (bt == 1) w = i < 18 ? w : i < 24 ? 1.0 : i < 30 ? sin(pi / 12 * (i - 18 + 0.5)) : 0.0;
                 if (bt == 3) w = i < 6 ? 0.0 : i < 12 ? sin(pi / 12 * (i - 6 + 0.5)) : i < 18 ? 1.0 : w;
-                for (int k = 0; k < 18; ++k)
-                    imdct_long[bt][i][k] = (float)(w * cos(pi / 72 * (2 * i + 19) * (2 * k + 1)));
+                long_window[bt][i] = (float)w;
             }
+        for (int r = 0; r < 18; ++r)
+            for (int k = 0; k < 18; ++k) {
+                const int i = r < 9 ? r : r + 9;
+                imdct_cos[r][k] = (float)cos(pi / 72 * (2 * i + 19) * (2 * k + 1));
+            }
+        for (int n = 2; n <= 32; n *= 2)
+            for (int k = 0; k < n / 2; ++k) lee[n / 2 + k] = 1.0 / (2.0 * cos((2 * k + 1) * pi / (2 * n)));
+        memset(first, 0, sizeof(first));
+        for (int t = 0; t <= 32; ++t) {
+            const int16_t(*nodes)[2] = t == 32 ? kMp3Book32 : kBooks[t].nodes;
+            if (!nodes) continue;
+            int16_t* f = first[t == 32 ? 16 : kBooks[t].id];
+            for (int w = 0; w < 256; ++w) {
+                int at = 0, used = 0;
+                while (at >= 0 && used < 8) at = nodes[at][(w >> (7 - used)) & 1], ++used;
+                f[w] = at < 0 ? (int16_t)(((-at - 1) << 4) | used) : (int16_t)(-at - 1);
+            }
+        }
         for (int i = 0; i < 12; ++i)
             for (int k = 0; k < 6; ++k)
                 imdct_short[i][k] = (float)(sin(pi / 12 * (i + 0.5)) * cos(pi / 24 * (2 * i + 7) * (2 * k + 1)));
-        for (int i = 0; i < 64; ++i)
-            for (int k = 0; k < 32; ++k) synth_cos[i][k] = (float)cos(pi / 64 * (16 + i) * (2 * k + 1));
         for (int n = 0; n < 512; ++n) {
             const double h = kWindowBase[n <= 256 ? n : 512 - n] / 65536.0;
             window[n] = (float)(((n >> 6) & 1) ? -h : h);
@@ -133,6 +153,27 @@ static const Tables& tables() {
     static const Tables t;
     return t;
 }
+
+// X[m] = sum_k x[k] cos((2k + 1) m pi / 2N), in place (Lee's recursion: two half-size transforms of the sums and of
+// the scaled differences).  Double precision: the scale factors reach 10 and multiply along the recursion.
+template <int N>
+static inline void dct2(double* x, const double* lee) {
+    double a[N / 2], b[N / 2];
+    for (int k = 0; k < N / 2; ++k) {
+        a[k] = x[k] + x[N - 1 - k];
+        b[k] = (x[k] - x[N - 1 - k]) * lee[N / 2 + k];
+    }
+    dct2<N / 2>(a, lee);
+    dct2<N / 2>(b, lee);
+    for (int m = 0; m < N / 2 - 1; ++m) {
+        x[2 * m] = a[m];
+        x[2 * m + 1] = b[m] + b[m + 1];
+    }
+    x[N - 2] = a[N / 2 - 1];
+    x[N - 1] = b[N / 2 - 1];
+}
+template <>
+inline void dct2<1>(double*, const double*) {}
 
 // ---- frame header -----------------------------------------------------------------------------------------------
 struct Header {
@@ -272,9 +313,15 @@ struct Bits {
         pos += n;
         return v;
     }
-    int walk(const int16_t (*nodes)[2]) {
+    int walk(const int16_t (*nodes)[2], const int16_t* first) {
         uint32_t w = peek32();
-        int at = 0, used = 0;
+        const int e = first[w >> 24];
+        if (e >= 0) {   // a code of at most 8 bits
+            pos += e & 15;
+            return e >> 4;
+        }
+        int at = -e - 1, used = 8;
+        w <<= 8;
         do {
             at = nodes[at][w >> 31];
             w <<= 1;
@@ -372,8 +419,9 @@ static bool parse_side_info(const uint8_t* p, const Header& h, SideInfo& si) {
 // per-channel state carried from frame to frame
 struct Channel {
     float overlap[32][18];
-    float v[1024];
+    float v[2048];    // synthesis history, every vector stored twice (at o and o + 1024) so that 1024 in a row are readable
     int voff;
+    int live;         // subbands whose overlap may be non-zero
     uint8_t scf_prev[40];   // granule 0's scale factors (for scfsi)
 };
 
@@ -475,7 +523,7 @@ struct Decoder {
                     over = true;
                     break;
                 }
-                const int v = b.walk(bk.nodes);
+                const int v = b.walk(bk.nodes, T.first[bk.id]);
                 int x = v >> 4, y = v & 15;
                 if (x == 15 && bk.linbits) x += b.get(bk.linbits);
                 if (x && b.get(1)) x = -x;
@@ -487,7 +535,7 @@ struct Decoder {
         }
         if (b.pos > end) over = true;
         while (!over && i <= 572 && b.pos < end) {
-            int v = g.count1_b ? (int)(15 - b.get(4)) : b.walk(kMp3Book32);
+            int v = g.count1_b ? (int)(15 - b.get(4)) : b.walk(kMp3Book32, T.first[16]);
             int q[4];
             for (int k = 0; k < 4; ++k) {
                 q[k] = (v >> (3 - k)) & 1;
@@ -620,16 +668,31 @@ struct Decoder {
                 xr[18 * sb - 1 - i] = lo * T.cs[i] - hi * T.ca[i];
                 xr[18 * sb + i] = hi * T.cs[i] + lo * T.ca[i];
             }
+        int top = 576;   // lines at and above `top` are zero
+        while (top > 0 && xr[top - 1] == 0.0f) --top;
+        const int coded = (top + 17) / 18;                      // subbands holding spectrum
+        const int busy = coded > c.live ? coded : c.live;       // ... or overlap from the granule before
         float slots[18][32];
-        for (int sb = 0; sb < 32; ++sb) {
+        for (int sb = busy; sb < 32; ++sb)
+            for (int i = 0; i < 18; ++i) slots[i][sb] = 0.0f;
+        for (int sb = 0; sb < busy; ++sb) {
             float y[36];
             const float* x = xr + 18 * sb;
-            if (sb < long_subbands) {
-                const float(*m)[18] = T.imdct_long[(g.block_type == 2) ? 0 : g.block_type];
-                for (int i = 0; i < 36; ++i) {
+            if (sb >= coded) {
+                memset(y, 0, sizeof(y));
+            } else if (sb < long_subbands) {
+                float raw[18];
+                for (int r = 0; r < 18; ++r) {
                     float a = 0;
-                    for (int k = 0; k < 18; ++k) a += m[i][k] * x[k];
-                    y[i] = a;
+                    for (int k = 0; k < 18; ++k) a += T.imdct_cos[r][k] * x[k];
+                    raw[r] = a;
+                }
+                const float* w = T.long_window[(g.block_type == 2) ? 0 : g.block_type];
+                for (int i = 0; i < 9; ++i) {   // outputs 17 - i and 53 - i mirror outputs i and 18 + i
+                    y[i] = w[i] * raw[i];
+                    y[17 - i] = -w[17 - i] * raw[i];
+                    y[18 + i] = w[18 + i] * raw[9 + i];
+                    y[35 - i] = w[35 - i] * raw[9 + i];
                 }
             } else {
                 memset(y, 0, sizeof(y));
@@ -647,23 +710,27 @@ struct Decoder {
                 slots[i][sb] = s;
             }
         }
+        c.live = coded;
         for (int t = 0; t < 18; ++t) {
+            // matrixing: v[i] = sum_k cos((16 + i)(2k + 1) pi / 64) s[k] from one 32-point DCT B[m]
+            double bq[32];
+            for (int k = 0; k < 32; ++k) bq[k] = slots[t][k];
+            dct2<32>(bq, T.lee);
             c.voff = (c.voff - 64) & 1023;
-            float* v = c.v;
-            const int vo = c.voff;
-            for (int i = 0; i < 64; ++i) {
-                float a = 0;
-                const float* n = T.synth_cos[i];
-                for (int k = 0; k < 32; ++k) a += n[k] * slots[t][k];
-                v[(vo + i) & 1023] = a;
+            float* v = c.v + c.voff;
+            for (int i = 0; i < 16; ++i) v[i] = (float)bq[16 + i];
+            v[16] = 0.0f;
+            for (int i = 17; i < 48; ++i) v[i] = (float)-bq[48 - i];
+            for (int i = 48; i < 64; ++i) v[i] = (float)-bq[i - 48];
+            memcpy(v + 1024, v, 64 * sizeof(float));
+            float acc[32];
+            for (int j = 0; j < 32; ++j) acc[j] = 0.0f;
+            for (int i = 0; i < 8; ++i) {
+                const float* w = T.window + 64 * i;
+                const float* va = v + 128 * i;
+                for (int j = 0; j < 32; ++j) acc[j] += w[j] * va[j] + w[32 + j] * va[96 + j];
             }
-            for (int j = 0; j < 32; ++j) {
-                float a = 0;
-                for (int i = 0; i < 8; ++i)
-                    a += T.window[64 * i + j] * v[(vo + 128 * i + j) & 1023] +
-                         T.window[64 * i + 32 + j] * v[(vo + 128 * i + 96 + j) & 1023];
-                pcm[(size_t)(32 * t + j) * stride] = a;
-            }
+            for (int j = 0; j < 32; ++j) pcm[(size_t)(32 * t + j) * stride] = acc[j];
         }
     }
 
