@@ -334,7 +334,7 @@ struct Bits {
 
 struct Granule {
     int part23, big_values, global_gain, scf_compress, block_type, table[3], sub_gain[3], region0, region1;
-    bool switching, mixed, preflag, scf_scale, count1_b;
+    bool switching, mixed, low_normal, preflag, scf_scale, count1_b;   // mixed: short granule with long low bands
     // flat band list in transmission order: long bands, then short bands (each band once per window)
     int n_long, n_bands;
     int16_t width[40];
@@ -390,7 +390,7 @@ static bool parse_side_info(const uint8_t* p, const Header& h, SideInfo& si) {
             g.global_gain = b.get(8);
             g.scf_compress = b.get(h.lsf ? 9 : 4);
             g.block_type = 0;
-            g.mixed = false;
+            g.mixed = g.low_normal = false;
             g.sub_gain[0] = g.sub_gain[1] = g.sub_gain[2] = 0;
             g.switching = b.get(1);
             if (g.switching) {
@@ -410,6 +410,9 @@ static bool parse_side_info(const uint8_t* p, const Header& h, SideInfo& si) {
             g.scf_scale = b.get(1);
             g.count1_b = b.get(1);
             if (g.big_values > 288) return false;
+            // the flag of a window-switching granule: its two lowest subbands keep the normal window whatever the block
+            // type; only a short granule also changes its band layout
+            g.low_normal = g.mixed;
             if (g.block_type != 2) g.mixed = false;
             build_bands(g, h);
         }
@@ -687,7 +690,7 @@ struct Decoder {
                     for (int k = 0; k < 18; ++k) a += T.imdct_cos[r][k] * x[k];
                     raw[r] = a;
                 }
-                const float* w = T.long_window[(g.block_type == 2) ? 0 : g.block_type];
+                const float* w = T.long_window[(g.block_type == 2 || (g.low_normal && sb < 2)) ? 0 : g.block_type];
                 for (int i = 0; i < 9; ++i) {   // outputs 17 - i and 53 - i mirror outputs i and 18 + i
                     y[i] = w[i] * raw[i];
                     y[17 - i] = -w[17 - i] * raw[i];

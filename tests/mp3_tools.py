@@ -104,9 +104,10 @@ _COS12 = np.cos(np.pi / 24 * (2 * np.arange(12)[:, None] + 7) * (2 * np.arange(6
 _WIN12 = np.sin(np.pi / 12 * (np.arange(12) + 0.5))
 
 
-def hybrid(sub, block_types):
+def hybrid(sub, block_types, mixed=False):
     """Subband samples [granules * 18, 32] -> spectra [granules, 576] in the order the inverse transform reads them
-    (long: line 18 sb + k; short: line 18 sb + 3 k + window), alias butterflies applied to long granules."""
+    (long: line 18 sb + k; short: line 18 sb + 3 k + window), alias butterflies applied between long subbands.
+    `mixed`: every window-switching granule keeps the normal long window in its two lowest subbands."""
     g_n = len(block_types)
     s = sub[: g_n * 18].reshape(g_n, 18, 32).copy()
     s[:, 1::2, 1::2] *= -1.0                                        # frequency inversion
@@ -115,40 +116,47 @@ def hybrid(sub, block_types):
     for g, bt in enumerate(block_types):
         z = np.concatenate([prev, s[g]], axis=0)                    # [36, 32]
         prev = s[g]
-        if bt != 2:
-            xr = ((z * _long_window(bt)[:, None]).T @ _COS36) / 9.0  # [32, 18]
+        if bt != 2 or mixed:
+            win = np.repeat(_long_window(bt if bt != 2 else 0)[:, None], 32, axis=1)
+            if mixed:
+                win[:, :2] = _long_window(0)[:, None]
+            xr = ((z * win).T @ _COS36) / 9.0                        # [32, 18]
             xr = xr.reshape(576)
-            for sb in range(1, 32):
+            for sb in range(1, 32 if bt != 2 else 2):
                 lo = xr[18 * sb - 1 - np.arange(8)].copy()
                 hi = xr[18 * sb + np.arange(8)].copy()
                 xr[18 * sb - 1 - np.arange(8)] = lo * CS + hi * CA
                 xr[18 * sb + np.arange(8)] = hi * CS - lo * CA
             out[g] = xr
-        else:
+        if bt == 2:
             for w in range(3):
                 seg = z[6 + 6 * w: 18 + 6 * w] * _WIN12[:, None]     # [12, 32]
                 xs = (seg.T @ _COS12) / 3.0                          # [32, 6]
-                out[g].reshape(32, 6, 3)[:, :, w] = xs
+                out[g].reshape(32, 6, 3)[2 if mixed else 0:, :, w] = xs[2 if mixed else 0:]
     return out
 
 
-def band_widths(sr_idx, bt):
+def band_widths(sr_idx, bt, mixed=False):
     if bt != 2:
         return list(np.diff(LONG_EDGES[sr_idx])), 22
-    w = []
-    for b in range(13):
+    w, n_long, first = [], 0, 0
+    if mixed:                                                       # long bands over the lowest 36 lines
+        n_long = int(np.searchsorted(LONG_EDGES[sr_idx], 36))
+        assert LONG_EDGES[sr_idx][n_long] == 36 and SHORT_EDGES[sr_idx][3] == 12
+        w, first = list(np.diff(LONG_EDGES[sr_idx][: n_long + 1])), 3
+    for b in range(first, 13):
         w += [int(SHORT_EDGES[sr_idx][b + 1] - SHORT_EDGES[sr_idx][b])] * 3
-    return w, 0
+    return w, n_long
 
 
-def to_flat(xr, sr_idx, bt):
+def to_flat(xr, sr_idx, bt, mixed=False):
     """Inverse-transform order -> transmission order (short granules: [band][window][line])."""
     if bt != 2:
         return xr.copy()
     q = xr.reshape(192, 3)                                          # [short line, window]
     se = SHORT_EDGES[sr_idx]
-    out = []
-    for b in range(13):
+    out = [xr[:36]] if mixed else []
+    for b in range(3 if mixed else 0, 13):
         for w in range(3):
             out.append(q[se[b]: se[b + 1], w])
     return np.concatenate(out)
@@ -178,9 +186,10 @@ def encode_granule(bw, isq, scf, gi, hdr, rng, opts):
     if not lsf:
         s1, s2 = SLEN[gi["scalefac_compress"]]
         if bt == 2:
-            for i in range(18):
+            n1 = 17 if gi.get("mixed") else 18                       # mixed: 8 long bands + short bands 3..5
+            for i in range(n1):
                 bw.put(int(scf[i]), s1)
-            for i in range(18, 36):
+            for i in range(n1, n1 + 18):
                 bw.put(int(scf[i]), s2)
         else:
             edges = [0, 6, 11, 16, 21]
@@ -190,7 +199,7 @@ def encode_granule(bw, isq, scf, gi, hdr, rng, opts):
                 for i in range(edges[k], edges[k + 1]):
                     bw.put(int(scf[i]), s1 if k < 2 else s2)
     else:
-        parts = [6, 5, 5, 5] if bt != 2 else [9, 9, 9, 9]
+        parts = gi.get("parts") or ([6, 5, 5, 5] if bt != 2 else [6, 9, 9, 9] if gi.get("mixed") else [9, 9, 9, 9])
         i = 0
         for k in range(4):
             for _ in range(parts[k]):
@@ -270,7 +279,7 @@ def _side_info(hdr, mdb, granules, scfsi):
             bw.put(1 if gi["switching"] else 0, 1)
             if gi["switching"]:
                 bw.put(gi["block_type"], 2)
-                bw.put(0, 1)
+                bw.put(1 if gi.get("mixed") else 0, 1)
                 bw.put(gi["tables"][0], 5)
                 bw.put(gi["tables"][1], 5)
                 for w in range(3):
@@ -298,8 +307,19 @@ def _crc16(data):
     return crc
 
 
+def intensity_gains(pos, lsf, scale_sel=0):
+    """(left, right) factors of an intensity-coded band, as the format defines them."""
+    if not lsf:
+        if pos == 6:
+            return 1.0, 0.0
+        r = np.tan(pos * np.pi / 12)
+        return r / (1 + r), 1 / (1 + r)
+    k = 2.0 ** (-0.25 * (((pos + 1) >> 1) << scale_sel))
+    return (k, 1.0) if pos & 1 else (1.0, k)
+
+
 def encode(pcm, rate, *, seed=0, ms=False, crc=False, block_types=None, peak_is=1000, scalefactors=False,
-           reservoir=False, tables=None, all_big=False):
+           reservoir=False, tables=None, all_big=False, mixed=False, intensity=None):
     """pcm float64 [n, channels] -> (stream bytes, info).  `peak_is`: the largest quantised magnitude a granule aims
     for (int, or a list to draw from per granule).  info: 'snr_spectrum_db' (signal power over quantisation-error
     power of everything written), 'granules', 'frames', 'tables_used'."""
@@ -322,10 +342,7 @@ def encode(pcm, rate, *, seed=0, ms=False, crc=False, block_types=None, peak_is=
     head_len = 4 + (2 if crc else 0) + hdr["side_bytes"]
     capacity = frame_bytes - head_len
 
-    spectra = [hybrid(analysis(pcm[:, c]), block_types) for c in range(ch)]
-    if ms:
-        m, s = (spectra[0] + spectra[1]) / np.sqrt(2), (spectra[0] - spectra[1]) / np.sqrt(2)
-        spectra = [m, s]
+    spectra = [hybrid(analysis(pcm[:, c]), block_types, mixed) for c in range(ch)]
     sig = err = 0.0
     area = bytearray()                       # main data of all frames, laid out as the slots of the frames
     wp = 0                                   # where the next frame's main data begins
@@ -339,13 +356,37 @@ def encode(pcm, rate, *, seed=0, ms=False, crc=False, block_types=None, peak_is=
             gidx = f * n_gr + g
             bt = block_types[gidx]
             row = []
+            mix = mixed and bt != 0
+            widths, n_long = band_widths(sr_idx, bt, mix)
+            flat = [to_flat(spectra[c][gidx], sr_idx, bt, mix) for c in range(ch)]
+            joint_from = 576                                         # first line that is intensity coded
+            first_joint_band = None
+            if intensity is not None:
+                starts = np.concatenate([[0], np.cumsum(widths)])
+                first_joint_band = next(b for b in range(len(widths)) if starts[b] >= intensity["bound"]
+                                        and (b < n_long or (b - n_long) % 3 == 0))
+                joint_from = int(starts[first_joint_band])
+                flat[1][joint_from:] = 0.0
+            if ms:
+                m = (flat[0][:joint_from] + flat[1][:joint_from]) / np.sqrt(2)
+                d = (flat[0][:joint_from] - flat[1][:joint_from]) / np.sqrt(2)
+                flat[0][:joint_from], flat[1][:joint_from] = m, d
             for c in range(ch):
-                xr = to_flat(spectra[c][gidx], sr_idx, bt)
-                widths, n_long = band_widths(sr_idx, bt)
+                xr = flat[c]
                 gi = {"granule": g, "block_type": bt, "switching": bt != 0, "sub_gain": [0, 0, 0], "preflag": 0,
-                      "scf_scale": 0, "scalefac_compress": 0, "region0": 0, "region1": 0, "scfsi": scfsi[c]}
+                      "scf_scale": 0, "scalefac_compress": 0, "region0": 0, "region1": 0, "scfsi": scfsi[c],
+                      "mixed": mix}
                 scf = np.zeros(40, dtype=np.int64)
-                if scalefactors:
+                if intensity is not None and c == 1:                  # the right channel's scale factors are positions
+                    n_sent = 21 if bt != 2 else (35 if (mix and not lsf) else 33 if mix else 36)
+                    scf[first_joint_band:n_sent] = intensity["pos"]
+                    if not lsf:
+                        gi["scalefac_compress"] = 15                 # 4 and 3 bits
+                    else:
+                        gi["slen"] = [3, 3, 3, 0]
+                        gi["scalefac_compress"] = (3 * 36 + 3 * 6 + 3) * 2 + intensity.get("scale_sel", 0)
+                        gi["parts"] = [7, 7, 7, 0] if bt != 2 else [6, 15, 12, 0] if mix else [12, 12, 12, 0]
+                elif scalefactors:
                     gi["scf_scale"] = int(rng.integers(2))
                     if bt == 2:
                         gi["sub_gain"] = [int(v) for v in rng.integers(0, 4, 3)]
@@ -354,8 +395,9 @@ def encode(pcm, rate, *, seed=0, ms=False, crc=False, block_types=None, peak_is=
                         s1, s2 = SLEN[gi["scalefac_compress"]]
                         gi["preflag"] = int(rng.integers(2)) if bt != 2 else 0
                         if bt == 2:
-                            scf[:18] = rng.integers(0, 1 << s1, 18)
-                            scf[18:36] = rng.integers(0, 1 << s2, 18)
+                            n1 = 17 if mix else 18
+                            scf[:n1] = rng.integers(0, 1 << s1, n1)
+                            scf[n1:n1 + 18] = rng.integers(0, 1 << s2, 18)
                         else:
                             scf[:11] = rng.integers(0, 1 << s1, 11)
                             scf[11:21] = rng.integers(0, 1 << s2, 10)
@@ -369,7 +411,7 @@ def encode(pcm, rate, *, seed=0, ms=False, crc=False, block_types=None, peak_is=
                         sl = [int(rng.integers(5)), int(rng.integers(5)), int(rng.integers(4)), int(rng.integers(4))]
                         gi["slen"] = sl
                         gi["scalefac_compress"] = ((sl[0] * 5 + sl[1]) << 4) | (sl[2] << 2) | sl[3]
-                        parts = [6, 5, 5, 5] if bt != 2 else [9, 9, 9, 9]
+                        parts = [6, 5, 5, 5] if bt != 2 else [6, 9, 9, 9] if mix else [9, 9, 9, 9]
                         i = 0
                         for k in range(4):
                             scf[i:i + parts[k]] = rng.integers(0, 1 << sl[k], parts[k])
@@ -384,10 +426,12 @@ def encode(pcm, rate, *, seed=0, ms=False, crc=False, block_types=None, peak_is=
                 mult = 4 if gi["scf_scale"] else 2
                 band_e = []
                 for b, w in enumerate(widths):
-                    if b < n_long:
+                    if intensity is not None and c == 1 and b >= first_joint_band:
+                        e = 0                                        # (a position, not a gain; the lines are zero)
+                    elif b < n_long:
                         e = -mult * (int(scf[b]) + (PRETAB[b] if gi["preflag"] else 0))
                     else:
-                        e = -8 * gi["sub_gain"][b % 3] - mult * int(scf[b])
+                        e = -8 * gi["sub_gain"][(b - n_long) % 3] - mult * int(scf[b])
                     band_e += [e] * int(w)
                 band_e = np.array(band_e, dtype=np.float64)
                 target = peak_is if np.isscalar(peak_is) else int(peak_is[rng.integers(len(peak_is))])
@@ -429,9 +473,11 @@ def encode(pcm, rate, *, seed=0, ms=False, crc=False, block_types=None, peak_is=
         if reservoir and rng.random() < 0.3:                         # some stuffing between frames' data
             wp = min(wp + int(rng.integers(0, 40)), slot + capacity)
         side = _side_info(hdr, mdb, granules, scfsi)
-        mode = 3 if ch == 1 else (1 if ms else 0)
+        joint = ms or intensity is not None
+        mode = 3 if ch == 1 else (1 if joint else 0)
         h = bytes([0xFF, 0xE0 | (ver_bits << 3) | (1 << 1) | (0 if crc else 1),
-                   (14 << 4) | ((sr_idx % 3) << 2), (mode << 6) | ((2 if ms else 0) << 4)])
+                   (14 << 4) | ((sr_idx % 3) << 2),
+                   (mode << 6) | (((2 if ms else 0) | (1 if intensity is not None else 0)) << 4)])
         out += h
         if crc:
             out += _crc16(h[2:4] + side).to_bytes(2, "big")

@@ -10,7 +10,7 @@ so the decoded samples are PARITY-UNPINNED against it.  What pins the decoder in
   * the format's own mathematics — a small encoder in tests/mp3_tools.py, written from the forward definitions
     (analysis filter bank, MDCT, quantiser): PCM -> encoder -> decoder must come back with the signal-to-noise ratio
     of the quantised spectrum, for every block type, stereo mode, sampling frequency, code book and scale-factor form.
-Intensity stereo and mixed blocks are decoded but reached by neither source (no test).
+Intensity stereo and mixed blocks do not occur in the recording; the encoder produces them.
 """
 import json
 
@@ -185,6 +185,51 @@ def test_every_code_book(tmp_path, table):
     assert info["tables_used"] == [table]
     # (a short, steeply coloured signal: the interior that is compared can be a little cleaner than the whole spectrum)
     assert -1.5 < snr - info["snr_spectrum_db"] < 4.0, (snr, info["snr_spectrum_db"])
+
+
+@pytest.mark.parametrize("rate", [44100, 48000, 22050, 16000])
+def test_mixed_blocks(tmp_path, rate):
+    """Window-switching granules with the mixed flag: the two lowest subbands keep the normal long window through
+    start, short and stop granules (and long scale-factor bands in the short one), the other thirty switch."""
+    rng = np.random.default_rng(rate + 1)
+    spf = 576 if rate < 32000 else 1152
+    plan = [0, 0, 1, 2, 2, 3, 0, 1, 2, 3]
+    for lo in (0, 15, 30, 300):
+        pcm = _band_noise(rng, spf * 14, rate, lo, 45)
+        snr, info = _roundtrip(tmp_path, pcm, rate, peak_is=3000, block_types=plan, mixed=True, seed=lo)
+        assert info["snr_spectrum_db"] > 35 and snr > info["snr_spectrum_db"] - 1.5, (lo, snr, info["snr_spectrum_db"])
+    pcm = _pink_noise(rng, spf * 24, 2)
+    snr, info = _roundtrip(tmp_path, pcm, rate, ms=True, crc=True, scalefactors=True, reservoir=True, mixed=True,
+                           peak_is=[2, 5, 15, 40], seed=5, block_types=plan)
+    assert abs(snr - info["snr_spectrum_db"]) < 1.5, (snr, info["snr_spectrum_db"])
+
+
+@pytest.mark.parametrize("rate,pos,ms,sel,plan", [(44100, p, m, 0, None) for p in range(7) for m in (False, True)]
+                         + [(22050, p, False, sel, None) for p in (0, 1, 2, 3, 6) for sel in (0, 1)]
+                         + [(48000, 2, True, 0, "switching"), (24000, 3, False, 1, "switching"),
+                            (44100, 4, False, 0, "mixed")])
+def test_intensity_stereo(tmp_path, rate, pos, ms, sel, plan):
+    """Above a bound the right channel carries no spectrum, only a position per band; both channels are the left
+    channel's spectrum times the two factors the position stands for.  Input: left = A + C, right = B with C above
+    the bound; expected output: left = A + kl C, right = B + kr C."""
+    rng = np.random.default_rng(rate + pos)
+    spf = 576 if rate < 32000 else 1152
+    n = spf * 14
+    a, b = _band_noise(rng, n, rate, 100, 50)[:, 0], _band_noise(rng, n, rate, 100, 50)[:, 0]
+    c = _band_noise(rng, n, rate, 250, 50)[:, 0]
+    blocks = None if plan is None else [0, 0, 1, 2, 2, 3, 0, 1, 2, 3]
+    data, info = mt.encode(np.stack([a + c, b], axis=1), rate, ms=ms, peak_is=600, seed=pos, block_types=blocks,
+                           mixed=plan == "mixed", intensity={"bound": 200, "pos": pos, "scale_sel": sel})
+    p = tmp_path / "i.mp3"
+    p.write_bytes(data)
+    y, _, diag = audio.read_mp3(p, diagnostics=True)
+    assert list(diag[:4]) == [info["frames"], 0, 0, 0]
+    kl, kr = mt.intensity_gains(pos, rate < 32000, sel)
+    lo, hi = 2 * spf, n - 2 * spf - DELAY
+    for ch, want in enumerate((a + kl * c, b + kr * c)):
+        got = y[lo + DELAY: hi + DELAY, ch].astype(np.float64)
+        snr = 10 * np.log10((want[lo:hi] ** 2).sum() / ((want[lo:hi] - got) ** 2).sum())
+        assert snr > 25, (rate, pos, ms, ch, snr)
 
 
 def test_damage_is_contained(tmp_path):
