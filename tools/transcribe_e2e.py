@@ -3,7 +3,10 @@
 disk, end to end - file read, decode, chunk plan, device path, CTC stage, segments - with the time spent in audio
 loading shown separately.
 Usage: transcribe_e2e.py [hours [rate [channels [width]]]]   WAV of synthetic noise + tone (width 2 or 3 bytes)
-       transcribe_e2e.py flac [repeats]               FLAC made of the reference upload's frames (tests/flac_tools.py)"""
+       transcribe_e2e.py flac [repeats]               FLAC made of the reference upload's frames (tests/flac_tools.py)
+       transcribe_e2e.py mp3 [repeats]                MP3 made of the audio frames of the reference's demo recording
+                                                      (40 s at 44.1 kHz joint stereo per repeat; the frame at each
+                                                      join finds another bit reservoir than it was written for)"""
 import os, sys, tempfile, time, wave
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -43,7 +46,23 @@ def write_flac(repeats: int):
     return path, want.shape[0] / rate / 3600.0
 
 
-if len(sys.argv) > 1 and sys.argv[1] == "flac":
+def write_mp3(repeats: int):
+    from omnilingual_asr import audio
+    d = (ROOT / "tests" / "golden" / "reference_demo_40s.mp3").read_bytes()
+    head = 10 + ((d[6] & 127) << 21 | (d[7] & 127) << 14 | (d[8] & 127) << 7 | (d[9] & 127))
+    body = d[head + 208:]                       # past the ID3v2 tag and the 208-byte Info frame
+    path = os.path.join(tempfile.gettempdir(), "oasr_e2e.mp3")
+    with open(path, "wb") as f:
+        f.write(d)
+        for _ in range(repeats - 1):
+            f.write(body)
+    rate, _, total = audio.mp3_info(path)
+    return path, total / rate / 3600.0
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "mp3":
+    path, hours = write_mp3(int(sys.argv[2]) if len(sys.argv) > 2 else 180)
+elif len(sys.argv) > 1 and sys.argv[1] == "flac":
     path, hours = write_flac(int(sys.argv[2]) if len(sys.argv) > 2 else 400)
 else:
     hours = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
