@@ -35,9 +35,25 @@ def _riff_chunks(data: bytes):
         pos += 8 + size + (size & 1)
 
 
+def _g711_table(law: str) -> np.ndarray:
+    """The 256 linear 16-bit values of ITU-T G.711 (telephone speech), as float32 / 32768."""
+    code = np.arange(256, dtype=np.int32)
+    if law == "ulaw":
+        u = ~code & 0xFF
+        mag = ((((u & 0x0F) << 3) + 0x84) << ((u >> 4) & 7)) - 0x84
+        lin = np.where(u & 0x80, -mag, mag)
+    else:
+        a = code ^ 0x55
+        exp, man = (a >> 4) & 7, a & 0x0F
+        mag = np.where(exp == 0, (man << 4) + 8, ((man << 4) + 0x108) << np.maximum(exp - 1, 0))
+        lin = np.where(a & 0x80, mag, -mag)
+    return (lin / 32768.0).astype(np.float32)
+
+
 def read_wav(path) -> tuple[np.ndarray, int]:
     """Decode a WAV file -> (float32 [frames, channels] in [-1, 1), sample_rate).
-    Supports PCM 8/16/24/32-bit and IEEE float 32/64 (also via WAVE_FORMAT_EXTENSIBLE)."""
+    Supports PCM 8/16/24/32-bit, IEEE float 32/64 and 8-bit G.711 A-law / mu-law (format tags 6 / 7), also via
+    WAVE_FORMAT_EXTENSIBLE."""
     path = Path(path)
     data = path.read_bytes()
     if data[:4] != b"RIFF":
@@ -74,6 +90,8 @@ def read_wav(path) -> tuple[np.ndarray, int]:
             raise UnsupportedAudioError(f"unsupported PCM width {bits}")
     elif tag == 3:
         x = np.frombuffer(raw, dtype="<f4" if bits == 32 else "<f8").astype(np.float32)
+    elif tag in (6, 7) and bits == 8:
+        x = _g711_table("alaw" if tag == 6 else "ulaw")[np.frombuffer(raw, dtype=np.uint8)]
     else:
         raise UnsupportedAudioError(f"unsupported WAV format tag {tag}")
     return x.reshape(n, channels), int(rate)
@@ -244,7 +262,7 @@ def _extended80(b: bytes) -> float:
 
 
 def read_aiff(path) -> tuple[np.ndarray, int]:
-    """Decode AIFF / AIFF-C with uncompressed samples ('NONE', 'twos', 'sowt', 'fl32', 'fl64')
+    """Decode AIFF / AIFF-C with uncompressed samples ('NONE', 'twos', 'sowt', 'fl32', 'fl64') or G.711 ('ulaw', 'alaw')
     -> (float32 [frames, channels] in [-1, 1), sample_rate)."""
     data = Path(path).read_bytes()
     if len(data) < 12 or data[:4] != b"FORM" or data[8:12] not in (b"AIFF", b"AIFC"):
@@ -274,6 +292,8 @@ def read_aiff(path) -> tuple[np.ndarray, int]:
         x = np.frombuffer(raw[: len(raw) // 4 * 4], dtype=">f4").astype(np.float32)
     elif kind in (b"fl64", b"FL64"):
         x = np.frombuffer(raw[: len(raw) // 8 * 8], dtype=">f8").astype(np.float32)
+    elif kind in (b"ulaw", b"ULAW", b"alaw", b"ALAW"):
+        x = _g711_table(kind.decode().lower())[np.frombuffer(raw, dtype=np.uint8)]
     elif kind in (b"NONE", b"twos", b"sowt"):
         order = "<" if kind == b"sowt" else ">"
         n = len(raw) // width

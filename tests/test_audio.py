@@ -45,6 +45,24 @@ def test_float_stereo_downmix(tmp_path):
     np.testing.assert_allclose(y, st.mean(axis=1), atol=1e-7)
 
 
+@pytest.mark.parametrize("tag,law", [(7, "ulaw"), (6, "alaw")])
+def test_g711_wav_matches_the_standard_library_expansion(tmp_path, tag, law):
+    """Telephone-speech WAVs (8-bit mu-law / A-law): every code against Python's own G.711 expansion (audioop)."""
+    import audioop
+    import warnings
+    codes = bytes(range(256)) * 2
+    p = tmp_path / "g711.wav"
+    p.write_bytes(_wav_bytes(tag, 8, 2, 8000, codes))
+    x, rate = audio.read_wav(p)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lin = audioop.ulaw2lin(codes, 2) if law == "ulaw" else audioop.alaw2lin(codes, 2)
+    want = np.frombuffer(lin, dtype="<i2").astype(np.float32) / 32768.0
+    assert rate == 8000 and x.shape == (256, 2) and np.array_equal(x.reshape(-1), want)
+    y = audio.load_audio_16k(p)
+    assert y.shape == (512,) and np.isfinite(y).all()
+
+
 def test_compressed_formats_raise(tmp_path):
     p = tmp_path / "a.mp3"
     p.write_bytes(b"ID3....")

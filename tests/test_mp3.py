@@ -22,6 +22,21 @@ from omnilingual_asr import audio
 import mp3_tools as mt
 
 
+def test_code_books_are_complete_prefix_codes_and_the_include_file_is_theirs():
+    """Every Huffman book: Kraft sum exactly 1 and no code a prefix of another (a wrong length or code cannot hide),
+    and csrc/mp3_tables.inc holds exactly the trees built from them."""
+    import re
+    gen = mt.books
+    for n in gen.BOOKS:
+        assert gen.check_book(n) == [], n
+    text = (mt.ROOT / "omnilingual-asr_amd" / "csrc" / "mp3_tables.inc").read_text()
+    for n in gen.BOOKS:
+        body = text[text.index("kMp3Book%d[" % n):]
+        body = body[body.index("=") + 1: body.index(";")]
+        nodes = [[int(a), int(b)] for a, b in re.findall(r"\{(-?\d+),(-?\d+)\}", body)]
+        assert nodes == gen.build_tree(n), n
+
+
 @pytest.fixture(scope="module")
 def demo(golden_dir):
     x, rate, diag = audio.read_mp3(golden_dir / "reference_demo_40s.mp3", diagnostics=True)
