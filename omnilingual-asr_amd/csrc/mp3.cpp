@@ -20,7 +20,6 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -259,7 +258,7 @@ static void scan_frames(const uint8_t* d, int64_t size, std::vector<FrameRef>& o
 
 // Info / Xing frame: where the identifier sits, -1 when the frame is ordinary audio.
 static int info_tag_offset(const uint8_t* f, const Header& h) {
-    const int at = 4 + h.side_bytes;   // (such a frame carries no CRC)
+    const int at = 4 + (h.crc ? 2 : 0) + h.side_bytes;   // where the main data of an audio frame would begin
     if (at + 8 > h.frame_bytes) return -1;
     if (memcmp(f + at, "Info", 4) == 0 || memcmp(f + at, "Xing", 4) == 0) return at;
     return -1;
