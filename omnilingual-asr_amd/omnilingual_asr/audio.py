@@ -173,7 +173,7 @@ def audio_duration(path) -> float:
     COMM chunk, FLAC STREAMINFO; MP3: its frame headers are counted); raises on anything unreadable."""
     with open(path, "rb") as f:
         head = f.read(1 << 16)
-    if head[:4] == b"RIFF":
+    if head[:4] == b"RIFF" and not _looks_like_mp3(head, path):
         return wav_duration(path)
     if head[:4] == b"FORM" and head[8:12] in (b"AIFF", b"AIFC"):
         pos = 12
@@ -385,6 +385,11 @@ def _looks_like_mp3(head: bytes, path) -> bool:
     """An ID3v2 tag (unless the name says FLAC, which may carry one too) or an MPEG audio Layer III frame header."""
     if head[:3] == b"ID3":
         return Path(path).suffix.lower() != ".flac"
+    if head[:4] == b"RIFF":      # MPEG Layer III in a WAVE container: the fmt chunk says so
+        with open(path, "rb") as f:
+            blob = f.read(4096)
+        at = blob.find(b"fmt ")
+        return at >= 0 and len(blob) >= at + 10 and struct.unpack_from("<H", blob, at + 8)[0] == 0x55
     return (len(head) >= 4 and head[0] == 0xFF and head[1] & 0xE0 == 0xE0 and (head[1] >> 3) & 3 != 1
             and (head[1] >> 1) & 3 == 1 and head[2] >> 4 not in (0, 15) and (head[2] >> 2) & 3 != 3)
 
@@ -394,7 +399,7 @@ def mp3_info(path) -> tuple[int, int, int]:
     import ctypes as C
 
     from . import _hip
-    buf = np.fromfile(path, dtype=np.uint8)
+    buf = _mp3_bytes(path)
     rate, channels, total = C.c_int32(), C.c_int32(), C.c_int64()
     try:
         _hip.check(_hip.lib().oasr_mp3_info(buf.ctypes.data, buf.size, C.byref(rate), C.byref(channels),
@@ -402,6 +407,19 @@ def mp3_info(path) -> tuple[int, int, int]:
     except _hip.OasrError as e:
         raise UnsupportedAudioError(str(e)) from e
     return int(rate.value), int(channels.value), int(total.value)
+
+
+def _mp3_bytes(path) -> np.ndarray:
+    """The file's bytes; for MPEG Layer III wrapped in RIFF/WAVE (format tag 0x55) the payload of its data chunk."""
+    buf = np.fromfile(path, dtype=np.uint8)
+    if buf.size >= 12 and bytes(buf[:4]) == b"RIFF" and bytes(buf[8:12]) == b"WAVE":
+        pos = 12
+        while pos + 8 <= buf.size:
+            n = int.from_bytes(bytes(buf[pos + 4: pos + 8]), "little")
+            if bytes(buf[pos: pos + 4]) == b"data":
+                return buf[pos + 8: pos + 8 + n]
+            pos += 8 + n + (n & 1)
+    return buf
 
 
 def read_mp3(path, diagnostics: bool = False):
@@ -412,7 +430,7 @@ def read_mp3(path, diagnostics: bool = False):
     import ctypes as C
 
     from . import _hip
-    buf = np.fromfile(path, dtype=np.uint8)
+    buf = _mp3_bytes(path)
     rate, channels, total = C.c_int32(), C.c_int32(), C.c_int64()
     L = _hip.lib()
     try:
@@ -434,7 +452,7 @@ def read_mp3_mono(path) -> tuple[np.ndarray, int]:
     import ctypes as C
 
     from . import _hip
-    buf = np.fromfile(path, dtype=np.uint8)
+    buf = _mp3_bytes(path)
     rate, channels, total = C.c_int32(), C.c_int32(), C.c_int64()
     L = _hip.lib()
     try:
@@ -459,7 +477,7 @@ def read_audio(path) -> tuple[np.ndarray, int]:
     with open(path, "rb") as f:
         head = f.read(12)
     if head[:4] == b"RIFF":
-        return read_wav(path)
+        return read_mp3(path) if _looks_like_mp3(head, path) else read_wav(path)
     if head[:4] == b"FORM":
         return read_aiff(path)
     if head[:4] == b"fLaC" or head[:3] == b"ID3" and Path(path).suffix.lower() == ".flac":

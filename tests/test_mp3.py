@@ -278,6 +278,23 @@ def test_damage_is_contained(tmp_path):
         audio.read_mp3(p)
 
 
+def test_mp3_inside_a_wave_container(tmp_path):
+    """Some recorders wrap the stream in RIFF/WAVE with format tag 0x55: the data chunk goes to the same decoder."""
+    import struct
+    rng = np.random.default_rng(9)
+    data, info = mt.encode(_pink_noise(rng, 1152 * 6, 2), 44100, peak_is=15, seed=9)
+    plain = tmp_path / "p.mp3"
+    plain.write_bytes(data)
+    fmt = struct.pack("<HHIIHHH", 0x55, 2, 44100, 40000, 1, 0, 12) + bytes(12)
+    wrapped = tmp_path / "w.wav"
+    wrapped.write_bytes(b"RIFF" + struct.pack("<I", 4 + 8 + len(fmt) + 8 + len(data)) + b"WAVE" + b"fmt " +
+                        struct.pack("<I", len(fmt)) + fmt + b"data" + struct.pack("<I", len(data)) + data)
+    a, ra = audio.read_audio(plain)
+    b, rb = audio.read_audio(wrapped)
+    assert ra == rb == 44100 and np.array_equal(a, b) and audio.audio_duration(wrapped) == a.shape[0] / 44100.0
+    assert np.array_equal(audio.load_audio_16k(wrapped), audio.load_audio_16k(plain))
+
+
 def test_mp3_through_transcribe(golden_dir, tiny_engine):
     """The reference's demo recording end to end on the CPU (oracle engine injected): 40 s at the default 30 s
     chunks -> two segments that tile the decoded duration."""

@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""Soak run of the public call: many files of random length, rate, width and channel count in sequence through one
+"""Soak run of the public call: many files of random length, rate, width and channel count (integer PCM WAVs, and
+every fifth file an MP3 from the test encoder: mono / stereo / mid-side, 8 - 48 kHz) in sequence through one
 pipeline (graph capture per shape bucket, buffer eviction, device-resident and host-resident sample paths), each
 checked against a second pipeline that runs eager launches on freshly decoded host samples.  Usage: soak.py [files]"""
 import struct, sys, tempfile, os
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "omnilingual-asr_amd"))
+sys.path.insert(0, str(ROOT / "tests"))
 import numpy as np
 import torch
 from omnilingual_asr import audio
@@ -24,16 +26,30 @@ for k in range(files):
     width = int(rng.choice([2, 2, 2, 3, 1]))
     seconds = float(rng.choice([0.02, 0.3, 1.0, 7.7, 29.99, 30.0, 30.01, 61.5, 95.0])) * float(rng.uniform(0.9, 1.1))
     n = max(1, int(seconds * rate)) * channels
-    if width == 1:
+    if k % 5 == 4:          # an MP3: at least one frame, at most ~8 s (the test encoder is a numpy program)
+        import mp3_tools
+        rate = int(rng.choice([8000, 16000, 22050, 32000, 44100, 48000]))
+        spf = 576 if rate < 32000 else 1152
+        frames = max(1, min(int(seconds * rate) // spf, 8 * rate // spf))
+        pcm = 0.2 * rng.standard_normal((frames * spf, channels))
+        pcm = np.cumsum(pcm, axis=0) * 0.05 + pcm * 0.2           # coloured, so that the granules fit their budget
+        data, _ = mp3_tools.encode(pcm / max(1.0, np.abs(pcm).max()), rate, ms=channels == 2 and bool(rng.integers(2)),
+                                   peak_is=[3, 7, 15], seed=k, reservoir=True,
+                                   block_types=[0, 0, 1, 2, 3, 0] if rng.integers(2) else None)
+        with open(path, "wb") as f:
+            f.write(data)
+        width, seconds = 0, frames * spf / rate
+    elif width == 1:
         payload = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
     elif width == 2:
         payload = (rng.standard_normal(n) * 4000).astype("<i2").tobytes()
     else:
         payload = (rng.standard_normal(n) * 1e6).astype("<i4").view(np.uint8).reshape(-1, 4)[:, :3].tobytes()
-    fmt = struct.pack("<HHIIHH", 1, channels, rate, rate * channels * width, channels * width, 8 * width)
-    with open(path, "wb") as f:
-        f.write(b"RIFF" + struct.pack("<I", 36 + len(payload)) + b"WAVEfmt " + struct.pack("<I", 16) + fmt +
-                b"data" + struct.pack("<I", len(payload)) + payload)
+    if width:
+        fmt = struct.pack("<HHIIHH", 1, channels, rate, rate * channels * width, channels * width, 8 * width)
+        with open(path, "wb") as f:
+            f.write(b"RIFF" + struct.pack("<I", 36 + len(payload)) + b"WAVEfmt " + struct.pack("<I", 16) + fmt +
+                    b"data" + struct.pack("<I", len(payload)) + payload)
     got = pipe.transcribe_with_retry(path)
     host = audio.load_audio_16k(path, lambda mono, r: ref.engine.resample_16k(mono, r).cpu().numpy())
     bounds = plan_chunks(host.shape[0], ref.chunk_seconds, ref.min_chunking_seconds)
