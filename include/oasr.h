@@ -292,6 +292,15 @@ int oasr_mp3_decode(const uint8_t* data, int64_t size, float* out, int64_t capac
  * and rounded to float32 once: what averaging the two-channel output in float64 gives); `out` holds `capacity` samples. */
 int oasr_mp3_decode_mono(const uint8_t* data, int64_t size, float* out, int64_t capacity, int64_t* written,
                          int64_t* diagnostics);
+/* A stream opened once (its frames found and counted) and decoded by sample ranges, so that a caller can work on
+ * one part of a long file while the next is being decoded: oasr_mp3_decode_mono_range writes the samples
+ * [first, first + count) of what oasr_mp3_decode_mono would deliver, bit for bit (each range starts 12 frames early
+ * and discards those).  `data` must stay readable until oasr_mp3_close; ranges may be decoded from several threads at once. */
+typedef struct oasr_mp3_stream oasr_mp3_stream;
+int oasr_mp3_open(const uint8_t* data, int64_t size, oasr_mp3_stream** stream, int32_t* sample_rate, int32_t* channels,
+                  int64_t* samples_per_channel);
+int oasr_mp3_decode_mono_range(const oasr_mp3_stream* stream, int64_t first, int64_t count, float* out);
+void oasr_mp3_close(oasr_mp3_stream* stream);
 
 /* LayerNorm (optionally followed by Swish) straight to e4m3 rows + per-row scale: byte-identical to
  * oasr_layernorm(out_bf16=1) followed by oasr_quant_fp8_rows, without the intermediate bf16 matrix.

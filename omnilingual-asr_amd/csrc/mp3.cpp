@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -866,9 +867,10 @@ struct Decoder {
 
 static const int kWarmFrames = 12;
 
-// Frames [first, last) of the plan -> out (positions relative to the whole stream); returns samples written per channel.
+// Frames [first, last) of the plan; of what they produce, the output samples [lo, hi) of the stream go to
+// out[(s - lo) * channels ...].
 static void decode_range(const uint8_t* d, const StreamPlan& sp, int64_t first, int64_t last, float* out,
-                         int64_t capacity, int64_t* diag, bool mono) {
+                         int64_t lo, int64_t hi, int64_t* diag, bool mono) {
     Decoder dec;
     const int nch = sp.frames.front().h.channels;
     const int nout = mono ? 1 : nch;
@@ -889,11 +891,11 @@ static void decode_range(const uint8_t* d, const StreamPlan& sp, int64_t first, 
         if (mono && nch == 2)   // the mean of the two channels, formed in double and rounded once
             for (int i = 0; i < spf; ++i) pcm[i] = (float)(((double)pcm[2 * i] + (double)pcm[2 * i + 1]) * 0.5);
         int64_t s0 = f * spf - sp.lead, n = spf, skip = 0;   // this frame covers output samples [s0, s0 + spf)
-        if (s0 < 0) skip = -s0;
+        if (s0 < lo) skip = lo - s0;
         if (s0 + n > sp.keep) n = sp.keep - s0;
-        if (s0 + n > capacity) n = capacity - s0;
+        if (s0 + n > hi) n = hi - s0;
         if (n > skip)
-            memcpy(out + (size_t)(s0 + skip) * nout, pcm.data() + (size_t)skip * nout, sizeof(float) * (size_t)(n - skip) * nout);
+            memcpy(out + (size_t)(s0 + skip - lo) * nout, pcm.data() + (size_t)skip * nout, sizeof(float) * (size_t)(n - skip) * nout);
     }
     for (int k = 0; k < 5; ++k) diag[k] = dec.diag[k];
 }
@@ -919,6 +921,59 @@ int oasr_mp3_info(const uint8_t* data, int64_t size, int32_t* sample_rate, int32
 
 }  // extern "C"
 
+// Output samples [lo, hi) of a planned stream -> out, by one or several threads on frame ranges.
+static void decode_window(const uint8_t* data, const mp3::StreamPlan& sp, int64_t lo, int64_t hi, float* out, bool mono,
+                          int64_t* diagnostics) {
+    const int spf = sp.frames.front().h.samples();
+    const int64_t all = (int64_t)sp.frames.size();
+    int64_t f0 = (lo + sp.lead) / spf, f1 = (hi + sp.lead + spf - 1) / spf;   // frames that hold the window
+    if (f0 > all) f0 = all;
+    if (f1 > all) f1 = all;
+    const int64_t nf = f1 > f0 ? f1 - f0 : 0;
+    int threads = 1;
+    if (const char* e = getenv("OASR_MP3_THREADS")) {
+        threads = atoi(e);
+    } else if (nf >= 4096) {
+        const unsigned hc = std::thread::hardware_concurrency();
+        threads = (int)(hc ? hc : 1);
+        if (threads > 16) threads = 16;
+        if (threads > nf / 1024) threads = (int)(nf / 1024);
+    }
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    if (threads > nf) threads = nf > 0 ? (int)nf : 1;
+    std::vector<int64_t> diag((size_t)threads * 5, 0);
+    if (threads == 1) {
+        mp3::decode_range(data, sp, f0, f1, out, lo, hi, diag.data(), mono);
+    } else {
+        std::vector<std::thread> pool;
+        bool spawn_failed = false;
+        for (int t = 0; t < threads; ++t) {
+            const int64_t a = f0 + nf * t / threads, b = f0 + nf * (t + 1) / threads;
+            try {
+                pool.emplace_back(mp3::decode_range, data, std::cref(sp), a, b, out, lo, hi, diag.data() + (size_t)t * 5,
+                                  mono);
+            } catch (...) {
+                spawn_failed = true;
+                break;
+            }
+        }
+        for (auto& th : pool) th.join();
+        if (spawn_failed) {   // a thread could not be started: decode everything in order instead
+            std::fill(diag.begin(), diag.end(), 0);
+            threads = 1;
+            mp3::decode_range(data, sp, f0, f1, out, lo, hi, diag.data(), mono);
+        }
+    }
+    if (diagnostics) {
+        for (int k = 0; k < 5; ++k) diagnostics[k] = 0;
+        for (int t = 0; t < threads; ++t)
+            for (int k = 0; k < 5; ++k) diagnostics[k] += diag[(size_t)t * 5 + k];
+        diagnostics[0] = nf;
+        diagnostics[1] = sp.skipped;
+    }
+}
+
 static int mp3_decode_to(const uint8_t* data, int64_t size, float* out, int64_t capacity_per_channel,
                          int64_t* written_per_channel, int64_t* diagnostics, bool mono) {
     OASR_REQUIRE(data && size > 0 && out && written_per_channel, "mp3_decode: null pointer");
@@ -931,52 +986,15 @@ static int mp3_decode_to(const uint8_t* data, int64_t size, float* out, int64_t 
                   (long long)sp.keep);
         return OASR_ECAPACITY;
     }
-    const int64_t nf = (int64_t)sp.frames.size();
-    int threads = 1;
-    if (const char* e = getenv("OASR_MP3_THREADS")) {
-        threads = atoi(e);
-    } else if (nf >= 4096) {
-        const unsigned hc = std::thread::hardware_concurrency();
-        threads = (int)(hc ? hc : 1);
-        if (threads > 16) threads = 16;
-        if (threads > nf / 1024) threads = (int)(nf / 1024);
-    }
-    if (threads < 1) threads = 1;
-    if (threads > 64) threads = 64;
-    if (threads > nf) threads = (int)nf;
-    std::vector<int64_t> diag((size_t)threads * 5, 0);
-    if (threads == 1) {
-        mp3::decode_range(data, sp, 0, nf, out, capacity_per_channel, diag.data(), mono);
-    } else {
-        std::vector<std::thread> pool;
-        bool spawn_failed = false;
-        for (int t = 0; t < threads; ++t) {
-            const int64_t a = nf * t / threads, b = nf * (t + 1) / threads;
-            try {
-                pool.emplace_back(mp3::decode_range, data, std::cref(sp), a, b, out, capacity_per_channel,
-                                  diag.data() + (size_t)t * 5, mono);
-            } catch (...) {
-                spawn_failed = true;
-                break;
-            }
-        }
-        for (auto& th : pool) th.join();
-        if (spawn_failed) {   // a thread could not be started: decode everything in order instead
-            std::fill(diag.begin(), diag.end(), 0);
-            threads = 1;
-            mp3::decode_range(data, sp, 0, nf, out, capacity_per_channel, diag.data(), mono);
-        }
-    }
+    decode_window(data, sp, 0, sp.keep, out, mono, diagnostics);
     *written_per_channel = sp.keep;
-    if (diagnostics) {
-        for (int k = 0; k < 5; ++k) diagnostics[k] = 0;
-        for (int t = 0; t < threads; ++t)
-            for (int k = 0; k < 5; ++k) diagnostics[k] += diag[(size_t)t * 5 + k];
-        diagnostics[0] = nf;
-        diagnostics[1] = sp.skipped;
-    }
     return OASR_OK;
 }
+
+struct oasr_mp3_stream {
+    const uint8_t* data;
+    mp3::StreamPlan plan;
+};
 
 extern "C" {
 
@@ -989,5 +1007,37 @@ int oasr_mp3_decode_mono(const uint8_t* data, int64_t size, float* out, int64_t 
                          int64_t* diagnostics) {
     return mp3_decode_to(data, size, out, capacity, written, diagnostics, true);
 }
+
+int oasr_mp3_open(const uint8_t* data, int64_t size, oasr_mp3_stream** stream, int32_t* sample_rate, int32_t* channels,
+                  int64_t* samples_per_channel) {
+    OASR_REQUIRE(data && size > 0 && stream && sample_rate && channels && samples_per_channel, "mp3_open: null pointer");
+    oasr_mp3_stream* s = new (std::nothrow) oasr_mp3_stream;
+    if (!s) {
+        set_error("mp3_open: out of host memory");
+        return OASR_ENOMEM;
+    }
+    s->data = data;
+    const int rc = mp3::plan_stream(data, size, s->plan);
+    if (rc != OASR_OK) {
+        delete s;
+        return rc;
+    }
+    *sample_rate = s->plan.frames.front().h.rate;
+    *channels = s->plan.frames.front().h.channels;
+    *samples_per_channel = s->plan.keep;
+    *stream = s;
+    return OASR_OK;
+}
+
+int oasr_mp3_decode_mono_range(const oasr_mp3_stream* stream, int64_t first, int64_t count, float* out) {
+    OASR_REQUIRE(stream && out, "mp3_decode_mono_range: null pointer");
+    OASR_REQUIRE(first >= 0 && count >= 0 && first + count <= stream->plan.keep,
+                 "mp3_decode_mono_range: samples %lld .. %lld lie outside the stream's %lld", (long long)first,
+                 (long long)(first + count), (long long)stream->plan.keep);
+    if (count > 0) decode_window(stream->data, stream->plan, first, first + count, out, true, nullptr);
+    return OASR_OK;
+}
+
+void oasr_mp3_close(oasr_mp3_stream* stream) { delete stream; }
 
 }  // extern "C"

@@ -467,6 +467,48 @@ def read_mp3_mono(path) -> tuple[np.ndarray, int]:
     return out[: written.value], int(rate.value)
 
 
+class Mp3Stream:
+    """An MP3 file opened once (frames found and counted) and decoded by sample ranges: `read_mono(first, count)`
+    returns the samples [first, first + count) of what `read_mp3_mono` delivers, bit for bit, so a caller can work on
+    one part of a long file while the next is being decoded.  Ranges may be read from several threads at once."""
+
+    def __init__(self, path):
+        import ctypes as C
+
+        from . import _hip
+        self._lib = _hip.lib()
+        self._buf = _mp3_bytes(path)             # must outlive the handle
+        rate, channels, total = C.c_int32(), C.c_int32(), C.c_int64()
+        self._handle = C.c_void_p()
+        try:
+            _hip.check(self._lib.oasr_mp3_open(self._buf.ctypes.data, self._buf.size, C.byref(self._handle),
+                                               C.byref(rate), C.byref(channels), C.byref(total)), "oasr_mp3_open")
+        except _hip.OasrError as e:
+            raise UnsupportedAudioError(str(e)) from e
+        self.rate, self.channels, self.samples = int(rate.value), int(channels.value), int(total.value)
+
+    def read_mono(self, first: int, count: int) -> np.ndarray:
+        from . import _hip
+        out = np.zeros((int(count),), dtype=np.float32)
+        _hip.check(self._lib.oasr_mp3_decode_mono_range(self._handle, int(first), int(count), out.ctypes.data),
+                   "oasr_mp3_decode_mono_range")
+        return out
+
+    def close(self) -> None:
+        if self._handle:
+            self._lib.oasr_mp3_close(self._handle)
+            self._handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        self.close()
+
+
 def is_mp3(path) -> bool:
     with open(path, "rb") as f:
         return _looks_like_mp3(f.read(12), path)

@@ -422,6 +422,70 @@ class GeminiASRPipeline:
             return records[0].to_result(word_timestamps=word_timestamps)
         return merge_results([self._transcribe_chunk(r, word_timestamps) for r in records])
 
+    def _encode_streamed(self, audio_path, word_timestamps: bool) -> Optional[GeminiTranscriptionResult]:
+        """A long MP3 in segments of two batches: host threads decode segment k + 1 while the device converts and
+        encodes segment k, instead of the whole file being decoded before the device starts.  Returns None when
+        the file or the engine is not of that kind (the ordinary path then runs).  The records equal the
+        ordinary path's bit for bit: every segment starts on a whole period of the rate converter and carries
+        enough input on both sides (a halo) for the converter's filter, so each 16 kHz sample is computed from
+        the same inputs by the same operations as in one pass over the file."""
+        from dataclasses import replace
+        from fractions import Fraction
+        eng = self.engine
+        if not (hasattr(eng, "submit") and hasattr(eng, "resample_16k")) or self.process_group is not None:
+            return None
+        if not _audio.is_mp3(audio_path):
+            return None
+        with _audio.Mp3Stream(audio_path) as stream:
+            rate, total = stream.rate, stream.samples
+            fr = Fraction(SAMPLE_RATE, rate)
+            up, down = fr.numerator, fr.denominator
+            n16 = -(-total * up // down)
+            bounds = plan_chunks(n16, self.chunk_seconds, self.min_chunking_seconds)
+            per_segment = 2 * self.batch_size
+            if len(bounds) < 2 * per_segment:
+                return None
+            firsts = list(range(0, len(bounds), per_segment))
+            if any(int(bounds[c][0]) % up for c in firsts):
+                return None                      # a segment would start inside a period of the converter
+            halo = 0
+            if rate != SAMPLE_RATE:
+                half = _audio.polyphase_branches(rate, SAMPLE_RATE)[2]
+                halo = down * -(-(half // up + 2) // down)
+
+            def span(c0):
+                c1 = min(c0 + per_segment, len(bounds))
+                a_out, b_out = int(bounds[c0][0]), int(bounds[c1 - 1][1])
+                a_in = a_out * down // up
+                b_in = total if c1 == len(bounds) else b_out * down // up
+                lo, hi = max(0, a_in - halo), min(total, b_in + halo)
+                return c1, a_out, b_out, a_in, lo, hi
+
+            from concurrent.futures import ThreadPoolExecutor
+            records: List[ChunkRecord] = []
+            with ThreadPoolExecutor(max_workers=1, thread_name_prefix="oasr-decode") as pool:
+                def fetch(c0):
+                    _, _, _, _, lo, hi = span(c0)
+                    return stream.read_mono(lo, hi - lo)
+                pending = pool.submit(fetch, firsts[0])
+                for i, c0 in enumerate(firsts):
+                    mono = pending.result()
+                    if i + 1 < len(firsts):
+                        pending = pool.submit(fetch, firsts[i + 1])
+                    c1, a_out, b_out, a_in, lo, hi = span(c0)
+                    with self._engine_lock:
+                        y = eng.resample_16k(mono, rate)
+                    drop = (a_in - lo) * up // down
+                    signal = y[drop: drop + (b_out - a_out)]
+                    if signal.shape[0] != b_out - a_out:
+                        raise ValueError("segment of %d samples where %d were planned" % (signal.shape[0], b_out - a_out))
+                    local = bounds[c0:c1] - a_out
+                    for r in self._encode_chunks(signal, local, first_idx=c0):
+                        records.append(replace(r, start_sample=r.start_sample + a_out, end_sample=r.end_sample + a_out))
+        if not records:
+            raise RuntimeError("none of the %d chunk(s) could be transcribed" % len(bounds))
+        return merge_results([self._transcribe_chunk(r, word_timestamps) for r in records])
+
     # ---- single-utterance entry (ref :474-539) ----------------------------------------------------------
     def transcribe(self, audio_path, *, progress_callback: Optional[Callable[[str, int], None]] = None,
                    language: Optional[str] = None, speaker_count: Optional[str] = None,
@@ -452,6 +516,12 @@ class GeminiASRPipeline:
                 progress_callback(step, idx)
 
         report("uploading", 0)
+        streamed = self._encode_streamed(audio_path, word_timestamps)   # long compressed file: decode and encode overlap
+        if streamed is not None:
+            report("transcribing", 1)
+            report("processing", 2)
+            report("done", 3)
+            return streamed
         pcm = self._load_audio(audio_path)
         bounds = plan_chunks(pcm.shape[0], self.chunk_seconds, self.min_chunking_seconds)
         if len(bounds) <= 1:

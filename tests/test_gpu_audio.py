@@ -145,6 +145,28 @@ def test_mp3_demo_through_the_device_path(golden_dir):
     assert segs[1].end == pytest.approx(got.shape[0] / 16000.0, abs=1e-6)
 
 
+@pytest.mark.parametrize("chunk_seconds", [5.0, 2.5])
+def test_long_mp3_in_segments_equals_the_one_pass_path(golden_dir, chunk_seconds):
+    """Decode of segment k + 1 overlapping the device's work on segment k (`_encode_streamed`): the same segments,
+    texts and times as decoding the whole file first, because every segment starts on a whole period of the rate
+    converter and carries the filter's reach on both sides."""
+    from omnilingual_asr import Pipeline
+
+    path = golden_dir / "reference_demo_40s.mp3"
+    pipe = Pipeline(model="GTINY", seed=4, batch_size=2, chunk_seconds=chunk_seconds,
+                    min_chunking_seconds=chunk_seconds).gemini
+    streamed = pipe._encode_streamed(path, True)
+    assert streamed is not None and len(streamed.segments) == -(-39953 // int(chunk_seconds * 1000))
+    pcm = pipe._load_audio(path)
+    whole = pipe._encode_file(pcm, True)
+    assert len(whole.segments) == len(streamed.segments)
+    for a, b in zip(streamed.segments, whole.segments):
+        assert (a.start, a.end, a.text) == (b.start, b.end, b.text) and a.words == b.words
+    assert any(s.text for s in whole.segments)
+    assert pipe.transcribe_chunked(path).segments == pipe._encode_streamed(path, False).segments   # the public entry takes it
+    assert Pipeline(model="GTINY", batch_size=32).gemini._encode_streamed(path, False) is None     # too short to split
+
+
 def test_host_only_call_before_the_engine_leaves_the_device_usable(golden_dir):
     """A host-only entry point (the FLAC decoder) used before any engine exists must not leave the process
     with a second HIP runtime: the library loader brings torch's in first.  Run in a child process, where

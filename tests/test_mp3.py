@@ -106,6 +106,23 @@ def test_mono_form_equals_the_float64_mean(golden_dir, monkeypatch):
     assert np.array_equal(y, audio.resample_poly(x.mean(axis=1, dtype=np.float64).astype(np.float32), rate))
 
 
+def test_ranges_of_an_opened_stream_equal_the_whole_decode(golden_dir, monkeypatch):
+    path = golden_dir / "reference_demo_40s.mp3"
+    whole, rate = audio.read_mp3_mono(path)
+    rng = np.random.default_rng(4)
+    with audio.Mp3Stream(path) as st:
+        assert (st.rate, st.channels, st.samples) == (rate, 2, whole.shape[0])
+        spans = [(0, 1), (0, 5000), (whole.shape[0] - 3, 3), (1151, 2), (0, whole.shape[0]), (777777, 0)]
+        spans += [(int(a), int(rng.integers(1, 300000))) for a in rng.integers(0, whole.shape[0] - 300000, 6)]
+        for th in ("1", "3"):
+            monkeypatch.setenv("OASR_MP3_THREADS", th)
+            for first, count in spans:
+                assert np.array_equal(st.read_mono(first, count), whole[first: first + count]), (th, first, count)
+        from omnilingual_asr import _hip
+        with pytest.raises(_hip.OasrError):
+            st.read_mono(whole.shape[0] - 2, 3)
+
+
 # ---- round trips through the test encoder ----------------------------------------------------------------------------
 def _band_noise(rng, n, rate, lo_line, lines, ch=1, amp=0.25):
     """Noise confined to MDCT lines [lo_line, lo_line + lines) of a 576-line granule."""
