@@ -91,6 +91,12 @@ def encode_sharded(pipeline, pcm: np.ndarray, bounds: np.ndarray, group=None) ->
     rank = dist.get_rank(group)
     lo, hi = shard_bounds(len(bounds), world, rank)
     mine = pipeline._encode_chunks(pcm, bounds[lo:hi], first_idx=lo)
+    return exchange_records(mine, bounds, group)
+
+
+def exchange_records(mine, bounds: np.ndarray, group=None) -> List:
+    """This rank's records (of its shard of `bounds`) in, the records of all ranks out, through the one all-gather."""
+    world = dist.get_world_size(group)
     # every rank derives the same token capacity from the plan: one token per 20 ms frame at most
     longest = int(max(e - s for s, e in bounds)) if len(bounds) else 0
     token_capacity = max(1, longest // 320)

@@ -424,7 +424,9 @@ class GeminiASRPipeline:
 
     def _encode_streamed(self, audio_path, word_timestamps: bool) -> Optional[GeminiTranscriptionResult]:
         """A long MP3 in segments of two batches: host threads decode segment k + 1 while the device converts and
-        encodes segment k, instead of the whole file being decoded before the device starts.  Returns None when
+        encodes segment k, instead of the whole file being decoded before the device starts.  Under a process
+        group a rank opens the stream and decodes only the samples of its own shard of chunks (the ordinary path
+        decodes the whole file on every rank); the records cross in the one all-gather.  Returns None when
         the file or the engine is not of that kind (the ordinary path then runs).  The records equal the
         ordinary path's bit for bit: every segment starts on a whole period of the rate converter and carries
         enough input on both sides (a halo) for the converter's filter, so each 16 kHz sample is computed from
@@ -432,7 +434,7 @@ class GeminiASRPipeline:
         from dataclasses import replace
         from fractions import Fraction
         eng = self.engine
-        if not (hasattr(eng, "submit") and hasattr(eng, "resample_16k")) or self.process_group is not None:
+        if not (hasattr(eng, "submit") and hasattr(eng, "resample_16k")):
             return None
         if not _audio.is_mp3(audio_path):
             return None
@@ -443,9 +445,17 @@ class GeminiASRPipeline:
             n16 = -(-total * up // down)
             bounds = plan_chunks(n16, self.chunk_seconds, self.min_chunking_seconds)
             per_segment = 2 * self.batch_size
-            if len(bounds) < 2 * per_segment:
+            c_lo, c_hi = 0, len(bounds)
+            if self.process_group is not None:
+                if len(bounds) <= 1:
+                    return None
+                import torch.distributed as dist
+                from omnilingual_asr import distributed as _dist
+                c_lo, c_hi = _dist.shard_bounds(len(bounds), dist.get_world_size(self.process_group),
+                                                dist.get_rank(self.process_group))
+            elif len(bounds) < 2 * per_segment:
                 return None
-            firsts = list(range(0, len(bounds), per_segment))
+            firsts = list(range(c_lo, c_hi, per_segment))
             if any(int(bounds[c][0]) % up for c in firsts):
                 return None                      # a segment would start inside a period of the converter
             halo = 0
@@ -454,7 +464,7 @@ class GeminiASRPipeline:
                 halo = down * -(-(half // up + 2) // down)
 
             def span(c0):
-                c1 = min(c0 + per_segment, len(bounds))
+                c1 = min(c0 + per_segment, c_hi)
                 a_out, b_out = int(bounds[c0][0]), int(bounds[c1 - 1][1])
                 a_in = a_out * down // up
                 b_in = total if c1 == len(bounds) else b_out * down // up
@@ -463,11 +473,13 @@ class GeminiASRPipeline:
 
             from concurrent.futures import ThreadPoolExecutor
             records: List[ChunkRecord] = []
+            self.decoded_source_samples = 0      # what this call decoded (a rank's share of the file, halos included)
             with ThreadPoolExecutor(max_workers=1, thread_name_prefix="oasr-decode") as pool:
                 def fetch(c0):
                     _, _, _, _, lo, hi = span(c0)
+                    self.decoded_source_samples += hi - lo
                     return stream.read_mono(lo, hi - lo)
-                pending = pool.submit(fetch, firsts[0])
+                pending = pool.submit(fetch, firsts[0]) if firsts else None
                 for i, c0 in enumerate(firsts):
                     mono = pending.result()
                     if i + 1 < len(firsts):
@@ -482,6 +494,8 @@ class GeminiASRPipeline:
                     local = bounds[c0:c1] - a_out
                     for r in self._encode_chunks(signal, local, first_idx=c0):
                         records.append(replace(r, start_sample=r.start_sample + a_out, end_sample=r.end_sample + a_out))
+        if self.process_group is not None:
+            records = _dist.exchange_records(records, bounds, self.process_group)
         if not records:
             raise RuntimeError("none of the %d chunk(s) could be transcribed" % len(bounds))
         return merge_results([self._transcribe_chunk(r, word_timestamps) for r in records])

@@ -261,6 +261,27 @@ def test_two_ranks_share_the_gpu_through_the_long_audio_mode():
     assert line["steps"] == 2 and line["value"] > 0            # 4 chunks per rank in batches of 3 + 1
 
 
+def test_two_ranks_decode_only_their_shards_of_an_mp3():
+    """Sharding a compressed file: two ranks (gloo, both on GPU 0) call the public long-audio entry on the reference's
+    demo recording; each decodes about half of it (its chunks plus the rate converter's reach), and the merged
+    result on every rank equals the unsharded one (tools/sharded_mp3.py)."""
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(root / "tools" / "sharded_mp3.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=str(root))
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("rank ")]
+    assert len(lines) == 2 and all("equal to the unsharded result: True" in l for l in lines), lines
+
+
 def test_four_threads_share_one_pipeline(tmp_path):
     """The reference's server runs up to four `transcribe()` calls at once on one shared instance
     (ref:workflows/wav2elan_web/app.py:383-399): results must equal the one-at-a-time results."""
