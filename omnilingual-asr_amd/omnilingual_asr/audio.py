@@ -476,6 +476,7 @@ class Mp3Stream:
         import ctypes as C
 
         from . import _hip
+        self._handle = None
         self._lib = _hip.lib()
         self._buf = _mp3_bytes(path)             # must outlive the handle
         rate, channels, total = C.c_int32(), C.c_int32(), C.c_int64()
@@ -489,15 +490,17 @@ class Mp3Stream:
 
     def read_mono(self, first: int, count: int) -> np.ndarray:
         from . import _hip
+        if not self._handle:
+            raise ValueError("the stream is closed")
         out = np.zeros((int(count),), dtype=np.float32)
         _hip.check(self._lib.oasr_mp3_decode_mono_range(self._handle, int(first), int(count), out.ctypes.data),
                    "oasr_mp3_decode_mono_range")
         return out
 
     def close(self) -> None:
-        if self._handle:
+        if getattr(self, "_handle", None):
             self._lib.oasr_mp3_close(self._handle)
-            self._handle = None
+        self._handle = None
 
     def __enter__(self):
         return self
