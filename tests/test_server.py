@@ -51,6 +51,18 @@ def test_transcribe_and_history_round_trip(client, golden_dir):
     assert client.get("/api/history/" + entry["id"]).json() == {"detail": "History entry not found."}
 
 
+def test_mp3_upload_is_transcribed(client, golden_dir):
+    """The upload type of the reference's demos (ref app.py:76-77 accepts .mp3): 40 s of its demo recording through
+    POST /api/transcribe; two 30 s-plan segments that cover the decoded duration."""
+    mp3 = (golden_dir / "reference_demo_40s.mp3").read_bytes()
+    r = client.post("/api/transcribe", files={"file": ("demo.mp3", mp3, "audio/mpeg")})
+    assert r.status_code == 200, r.text
+    entry = r.json()
+    assert entry["file_name"] == "demo.mp3" and entry["audio_url"].endswith(".mp3")
+    segs = entry["segments"]
+    assert [s["start"] for s in segs] == [0.0, 30.0] and abs(segs[1]["end"] - 39.953) < 0.01 and all(s["text"] for s in segs)
+
+
 def test_upload_validation_messages(client):
     assert client.post("/api/transcribe", files={"file": ("notes.txt", b"x", "text/plain")}).json() == {"detail": "Unsupported file type."}
     assert client.post("/api/transcribe", files={"file": ("a.zip", b"PK", "application/zip")}).json() == \
