@@ -68,6 +68,13 @@ int oasr_plan_chunks(int64_t total_samples, int32_t sample_rate, double chunk_se
  * (ref gemini_pipeline.py:623-641), whose results are re-ordered only at merge (:647-654). */
 int oasr_shard_range(int64_t n_items, int32_t world, int32_t rank, int64_t* lo, int64_t* hi);
 
+/* IMA / DVI ADPCM as WAV files hold it (format tag 0x11; dictaphones, field recorders - a WAV the reference's ffmpeg
+ * path takes, ref gemini_pipeline.py:273-285): `data` = the data chunk, blocks of `block_align` bytes, each a 4-byte
+ * header per channel (first sample, step index) followed by 4-byte groups of 8 codes per channel in turn, low nibble
+ * first.  Writes interleaved int16; a trailing partial block is ignored. */
+int oasr_adpcm_ima_decode(const uint8_t* data, int64_t size, int32_t channels, int32_t block_align, int16_t* out,
+                          int64_t capacity_per_channel, int64_t* written_per_channel);
+
 /* Number of 25 ms frames (hop 10 ms, no centring) in n_samples, and of stacked frame pairs. */
 int64_t oasr_num_frames(int64_t n_samples);
 int64_t oasr_num_stacked(int64_t n_samples);

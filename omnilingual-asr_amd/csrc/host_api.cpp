@@ -166,6 +166,57 @@ int oasr_shard_range(int64_t n_items, int32_t world, int32_t rank, int64_t* lo, 
     return OASR_OK;
 }
 
+int oasr_adpcm_ima_decode(const uint8_t* data, int64_t size, int32_t channels, int32_t block_align, int16_t* out,
+                          int64_t capacity_per_channel, int64_t* written_per_channel) {
+    OASR_REQUIRE(data && out && written_per_channel && size >= 0, "adpcm_ima_decode: null pointer");
+    OASR_REQUIRE(channels >= 1 && channels <= 8 && block_align >= 4 * channels && block_align % (4 * channels) == 0,
+                 "adpcm_ima_decode: a block is a 4-byte header and whole 4-byte groups per channel");
+    static const int16_t steps[89] = {
+        7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 19, 21, 23, 25, 28, 31, 34, 37, 41, 45, 50, 55, 60, 66, 73, 80, 88, 97, 107, 118,
+        130, 143, 157, 173, 190, 209, 230, 253, 279, 307, 337, 371, 408, 449, 494, 544, 598, 658, 724, 796, 876, 963, 1060,
+        1166, 1282, 1411, 1552, 1707, 1878, 2066, 2272, 2499, 2749, 3024, 3327, 3660, 4026, 4428, 4871, 5358, 5894, 6484,
+        7132, 7845, 8630, 9493, 10442, 11487, 12635, 13899, 15289, 16818, 18500, 20350, 22385, 24623, 27086, 29794, 32767};
+    static const int8_t moves[8] = {-1, -1, -1, -1, 2, 4, 6, 8};
+    const int64_t per_block = 1 + (int64_t)(block_align / channels - 4) * 2;   // samples per channel in a block
+    int64_t done = 0;
+    for (int64_t at = 0; at + block_align <= size; at += block_align) {
+        if (done + per_block > capacity_per_channel) {
+            set_error("adpcm_ima_decode: output holds %lld samples per channel, the data has more", (long long)capacity_per_channel);
+            return OASR_ECAPACITY;
+        }
+        const uint8_t* blk = data + at;
+        for (int c = 0; c < channels; ++c) {
+            int pred = (int16_t)(blk[4 * c] | (blk[4 * c + 1] << 8));
+            int idx = blk[4 * c + 2];
+            if (idx > 88) idx = 88;
+            int16_t* o = out + done * channels + c;
+            *o = (int16_t)pred;
+            int64_t n = 1;
+            // after the headers: groups of 4 bytes (8 samples, low nibble first) per channel, channels in turn
+            for (int g = 0; 4 * channels + (g * channels + c) * 4 + 4 <= block_align; ++g) {
+                const uint8_t* q = blk + 4 * channels + (g * channels + c) * 4;
+                for (int k = 0; k < 8; ++k) {
+                    const int code = (q[k >> 1] >> ((k & 1) * 4)) & 15;
+                    const int step = steps[idx];
+                    int diff = step >> 3;
+                    if (code & 4) diff += step;
+                    if (code & 2) diff += step >> 1;
+                    if (code & 1) diff += step >> 2;
+                    pred += (code & 8) ? -diff : diff;
+                    pred = pred > 32767 ? 32767 : pred < -32768 ? -32768 : pred;
+                    idx += moves[code & 7];
+                    idx = idx < 0 ? 0 : idx > 88 ? 88 : idx;
+                    o[n * channels] = (int16_t)pred;
+                    ++n;
+                }
+            }
+        }
+        done += per_block;
+    }
+    *written_per_channel = done;
+    return OASR_OK;
+}
+
 int64_t oasr_num_frames(int64_t n) {
     return n < OASR_FRAME_LEN ? 0 : 1 + (n - OASR_FRAME_LEN) / OASR_FRAME_HOP;
 }

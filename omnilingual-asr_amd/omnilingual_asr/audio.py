@@ -52,8 +52,8 @@ def _g711_table(law: str) -> np.ndarray:
 
 def read_wav(path) -> tuple[np.ndarray, int]:
     """Decode a WAV file -> (float32 [frames, channels] in [-1, 1), sample_rate).
-    Supports PCM 8/16/24/32-bit, IEEE float 32/64 and 8-bit G.711 A-law / mu-law (format tags 6 / 7), also via
-    WAVE_FORMAT_EXTENSIBLE."""
+    Supports PCM 8/16/24/32-bit, IEEE float 32/64, 8-bit G.711 A-law / mu-law (format tags 6 / 7) and 4-bit IMA ADPCM
+    (tag 0x11, decoded by the native library), also via WAVE_FORMAT_EXTENSIBLE."""
     path = Path(path)
     data = path.read_bytes()
     if data[:4] != b"RIFF":
@@ -92,6 +92,25 @@ def read_wav(path) -> tuple[np.ndarray, int]:
         x = np.frombuffer(raw, dtype="<f4" if bits == 32 else "<f8").astype(np.float32)
     elif tag in (6, 7) and bits == 8:
         x = _g711_table("alaw" if tag == 6 else "ulaw")[np.frombuffer(raw, dtype=np.uint8)]
+    elif tag == 0x11 and bits == 4:
+        import ctypes as C
+
+        from . import _hip
+        body = np.frombuffer(payload, dtype=np.uint8)
+        blocks = len(payload) // block
+        per_block = 1 + (block // channels - 4) * 2
+        out = np.zeros((max(blocks * per_block, 1), channels), dtype=np.int16)
+        written = C.c_int64()
+        try:
+            _hip.check(_hip.lib().oasr_adpcm_ima_decode(body.ctypes.data, body.size, channels, block, out.ctypes.data,
+                                                        out.shape[0], C.byref(written)), "oasr_adpcm_ima_decode")
+        except _hip.OasrError as e:
+            raise UnsupportedAudioError(str(e)) from e
+        n = written.value
+        fact = next((b for cid, b in _riff_chunks(data) if cid == b"fact" and len(b) >= 4), None)
+        if fact is not None:                     # the sample count the writer states (the last block may be padded)
+            n = min(n, struct.unpack_from("<I", fact, 0)[0])
+        return out[:n].astype(np.float32) / 32768.0, int(rate)
     else:
         raise UnsupportedAudioError(f"unsupported WAV format tag {tag}")
     return x.reshape(n, channels), int(rate)
@@ -151,6 +170,7 @@ def wav_duration(path) -> float:
     with open(path, "rb") as f:
         head = f.read(1 << 16)
     rate = block = None
+    per_block, stated = 1, 0
     pos = 12
     if head[:4] != b"RIFF" or head[8:12] != b"WAVE":
         raise UnsupportedAudioError("not a RIFF/WAVE file")
@@ -158,12 +178,19 @@ def wav_duration(path) -> float:
         cid = head[pos:pos + 4]
         size = struct.unpack_from("<I", head, pos + 4)[0]
         if cid == b"fmt ":
-            _, _, rate, _, block, _ = struct.unpack_from("<HHIIHH", head, pos + 8)
+            tag, channels, rate, _, block, _ = struct.unpack_from("<HHIIHH", head, pos + 8)
+            if tag == 0xFFFE and size >= 26:
+                tag = struct.unpack_from("<H", head, pos + 8 + 24)[0]
+            if tag == 0x11 and channels and block >= 4 * channels:      # IMA ADPCM: a block holds many samples
+                per_block = 1 + (block // channels - 4) * 2
+        elif cid == b"fact" and size >= 4:
+            stated = struct.unpack_from("<I", head, pos + 8)[0]
         elif cid == b"data":
             if not rate or not block:
                 break
             avail = Path(path).stat().st_size - (pos + 8)
-            return min(size, max(avail, 0)) // block / float(rate)
+            frames = min(size, max(avail, 0)) // block * per_block
+            return (min(frames, stated) if per_block > 1 and stated else frames) / float(rate)
         pos += 8 + size + (size & 1)
     raise UnsupportedAudioError("WAV header incomplete")
 

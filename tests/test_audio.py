@@ -63,6 +63,50 @@ def test_g711_wav_matches_the_standard_library_expansion(tmp_path, tag, law):
     assert y.shape == (512,) and np.isfinite(y).all()
 
 
+@pytest.mark.parametrize("channels", [1, 2])
+def test_ima_adpcm_wav_matches_the_standard_library_decoder(tmp_path, channels):
+    """4-bit IMA / DVI ADPCM WAVs: blocks built from Python's own encoder (audioop.lin2adpcm, nibbles re-packed low
+    first as WAV wants them), decoded by the native library, compared with audioop.adpcm2lin sample for sample."""
+    import audioop
+    import warnings
+    rng = np.random.default_rng(channels)
+    block, rate = 256 * channels, 8000
+    per_block = 1 + (block // channels - 4) * 2
+    n_blocks = 9
+    t = np.arange(n_blocks * per_block)
+    sig = [(np.sin(t * (0.02 + 0.01 * c)) * np.linspace(50, 30000, t.size) + rng.integers(-40, 40, t.size)).astype("<i2")
+           for c in range(channels)]
+    payload, want = bytearray(), np.zeros((t.size, channels), dtype=np.int16)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        index = [int(rng.integers(0, 89)) for _ in range(channels)]
+        for b in range(n_blocks):
+            seg = [s[b * per_block:(b + 1) * per_block] for s in sig]
+            coded = []
+            for c in range(channels):
+                state = (int(seg[c][0]), index[c])
+                payload += struct.pack("<hBB", state[0], state[1], 0)
+                adpcm, new_state = audioop.lin2adpcm(seg[c][1:].tobytes(), 2, state)
+                lin, _ = audioop.adpcm2lin(adpcm, 2, state)
+                want[b * per_block, c] = seg[c][0]
+                want[b * per_block + 1:(b + 1) * per_block, c] = np.frombuffer(lin, dtype="<i2")
+                coded.append(bytes(((v >> 4) | (v << 4)) & 0xFF for v in adpcm))     # first code into the low nibble
+                index[c] = new_state[1]
+            for g in range(len(coded[0]) // 4):
+                for c in range(channels):
+                    payload += coded[c][4 * g: 4 * g + 4]
+    fmt = struct.pack("<HHIIHHHH", 0x11, channels, rate, rate * block // per_block, block, 4, 2, per_block)
+    stated = t.size - 5                                                  # the writer's count: the last block is padded
+    body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"fact" + struct.pack("<II", 4, stated) \
+        + b"data" + struct.pack("<I", len(payload)) + bytes(payload)
+    p = tmp_path / "ima.wav"
+    p.write_bytes(b"RIFF" + struct.pack("<I", len(body)) + body)
+    x, r = audio.read_wav(p)
+    assert r == rate and x.shape == (stated, channels)
+    assert np.array_equal(x, want[:stated].astype(np.float32) / 32768.0)
+    assert audio.audio_duration(p) == stated / rate and audio.load_audio_16k(p).shape == (stated * 2,)
+
+
 def test_compressed_formats_raise(tmp_path):
     p = tmp_path / "a.mp3"
     p.write_bytes(b"ID3....")
