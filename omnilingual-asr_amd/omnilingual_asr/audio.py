@@ -24,13 +24,26 @@ class UnsupportedAudioError(RuntimeError):
     pass
 
 
+_RIFF_MAGICS = (b"RIFF", b"RF64", b"BW64")   # the 64-bit forms carry their real sizes in a 'ds64' chunk
+
+
+def _chunk_size(cid: bytes, size: int, ds64_data: int, remaining: int) -> int:
+    """A chunk's length: 0xFFFFFFFF stands for "see ds64" in the 64-bit forms and for "to the end of the file" in
+    a RIFF written as a stream; never more than the file holds."""
+    if size == 0xFFFFFFFF:
+        size = ds64_data if (cid == b"data" and ds64_data) else remaining
+    return min(size, remaining)
+
+
 def _riff_chunks(data: bytes):
-    if len(data) < 12 or data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+    if len(data) < 12 or data[:4] not in _RIFF_MAGICS or data[8:12] != b"WAVE":
         raise UnsupportedAudioError("not a RIFF/WAVE file")
-    pos = 12
+    pos, ds64_data = 12, 0
     while pos + 8 <= len(data):
         cid = data[pos:pos + 4]
-        size = struct.unpack_from("<I", data, pos + 4)[0]
+        size = _chunk_size(cid, struct.unpack_from("<I", data, pos + 4)[0], ds64_data, len(data) - pos - 8)
+        if cid == b"ds64" and size >= 16:
+            ds64_data = struct.unpack_from("<Q", data, pos + 16)[0]
         yield cid, data[pos + 8: pos + 8 + size]
         pos += 8 + size + (size & 1)
 
@@ -56,7 +69,7 @@ def read_wav(path) -> tuple[np.ndarray, int]:
     (tag 0x11, decoded by the native library), also via WAVE_FORMAT_EXTENSIBLE."""
     path = Path(path)
     data = path.read_bytes()
-    if data[:4] != b"RIFF":
+    if data[:4] not in _RIFF_MAGICS:
         raise UnsupportedAudioError(
             f"cannot decode '{path.suffix}' audio: WAV, AIFF, FLAC and MP3 input is supported")
     fmt = payload = None
@@ -127,13 +140,15 @@ def map_wav_pcm(path):
         if size < 44:
             return None
         mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
-    if mm[:4] != b"RIFF" or mm[8:12] != b"WAVE":
+    if mm[:4] not in _RIFF_MAGICS or mm[8:12] != b"WAVE":
         return None
     fmt = data_at = data_len = None
-    pos = 12
+    pos, ds64_data = 12, 0
     while pos + 8 <= size:
         cid = mm[pos:pos + 4]
-        n = struct.unpack_from("<I", mm, pos + 4)[0]
+        n = _chunk_size(cid, struct.unpack_from("<I", mm, pos + 4)[0], ds64_data, size - pos - 8)
+        if cid == b"ds64" and n >= 16:
+            ds64_data = struct.unpack_from("<Q", mm, pos + 16)[0]
         if cid == b"fmt ":
             fmt = mm[pos + 8: pos + 8 + min(n, 40)]
         elif cid == b"data":
@@ -172,11 +187,14 @@ def wav_duration(path) -> float:
     rate = block = None
     per_block, stated = 1, 0
     pos = 12
-    if head[:4] != b"RIFF" or head[8:12] != b"WAVE":
+    if head[:4] not in _RIFF_MAGICS or head[8:12] != b"WAVE":
         raise UnsupportedAudioError("not a RIFF/WAVE file")
+    file_size, ds64_data = Path(path).stat().st_size, 0
     while pos + 8 <= len(head):
         cid = head[pos:pos + 4]
-        size = struct.unpack_from("<I", head, pos + 4)[0]
+        size = _chunk_size(cid, struct.unpack_from("<I", head, pos + 4)[0], ds64_data, file_size - pos - 8)
+        if cid == b"ds64" and size >= 16 and pos + 24 <= len(head):
+            ds64_data = struct.unpack_from("<Q", head, pos + 16)[0]
         if cid == b"fmt ":
             tag, channels, rate, _, block, _ = struct.unpack_from("<HHIIHH", head, pos + 8)
             if tag == 0xFFFE and size >= 26:
@@ -200,7 +218,7 @@ def audio_duration(path) -> float:
     COMM chunk, FLAC STREAMINFO; MP3: its frame headers are counted); raises on anything unreadable."""
     with open(path, "rb") as f:
         head = f.read(1 << 16)
-    if head[:4] == b"RIFF" and not _looks_like_mp3(head, path):
+    if head[:4] in _RIFF_MAGICS and not _looks_like_mp3(head, path):
         return wav_duration(path)
     if head[:4] == b"FORM" and head[8:12] in (b"AIFF", b"AIFC"):
         pos = 12
@@ -412,7 +430,7 @@ def _looks_like_mp3(head: bytes, path) -> bool:
     """An ID3v2 tag (unless the name says FLAC, which may carry one too) or an MPEG audio Layer III frame header."""
     if head[:3] == b"ID3":
         return Path(path).suffix.lower() != ".flac"
-    if head[:4] == b"RIFF":      # MPEG Layer III in a WAVE container: the fmt chunk says so
+    if head[:4] in _RIFF_MAGICS:      # MPEG Layer III in a WAVE container: the fmt chunk says so
         with open(path, "rb") as f:
             blob = f.read(4096)
         at = blob.find(b"fmt ")
@@ -439,7 +457,7 @@ def mp3_info(path) -> tuple[int, int, int]:
 def _mp3_bytes(path) -> np.ndarray:
     """The file's bytes; for MPEG Layer III wrapped in RIFF/WAVE (format tag 0x55) the payload of its data chunk."""
     buf = np.fromfile(path, dtype=np.uint8)
-    if buf.size >= 12 and bytes(buf[:4]) == b"RIFF" and bytes(buf[8:12]) == b"WAVE":
+    if buf.size >= 12 and bytes(buf[:4]) in _RIFF_MAGICS and bytes(buf[8:12]) == b"WAVE":
         pos = 12
         while pos + 8 <= buf.size:
             n = int.from_bytes(bytes(buf[pos + 4: pos + 8]), "little")
@@ -548,7 +566,7 @@ def read_audio(path) -> tuple[np.ndarray, int]:
     """Decode by content: (float32 [frames, channels], sample_rate)."""
     with open(path, "rb") as f:
         head = f.read(12)
-    if head[:4] == b"RIFF":
+    if head[:4] in _RIFF_MAGICS:
         return read_mp3(path) if _looks_like_mp3(head, path) else read_wav(path)
     if head[:4] == b"FORM":
         return read_aiff(path)
@@ -568,7 +586,7 @@ def load_audio_16k(path, resampler=None, keep_int16: bool = False) -> np.ndarray
     it copies chunks into batches, so a long file is neither converted nor copied as a whole."""
     if keep_int16:
         with open(path, "rb") as f:
-            is_riff = f.read(4) == b"RIFF"
+            is_riff = f.read(4) in _RIFF_MAGICS
         fast = read_wav_pcm16_mono(path) if is_riff else None
         if fast is not None and fast[1] == TARGET_RATE:
             return fast[0]

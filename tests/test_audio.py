@@ -107,6 +107,28 @@ def test_ima_adpcm_wav_matches_the_standard_library_decoder(tmp_path, channels):
     assert audio.audio_duration(p) == stated / rate and audio.load_audio_16k(p).shape == (stated * 2,)
 
 
+@pytest.mark.parametrize("magic,trailer", [(b"RF64", b""), (b"BW64", b"LIST" + struct.pack("<I", 4) + b"abcd"),
+                                           (b"RIFF", b"")])
+def test_wav_beyond_four_gigabytes_forms(tmp_path, magic, trailer):
+    """A WAV of many hours exceeds RIFF's 32-bit sizes: RF64 / BW64 keep the real sizes in a 'ds64' chunk and put
+    0xFFFFFFFF in the 32-bit fields (chunks may follow the data); a RIFF written as a stream carries 0xFFFFFFFF
+    and runs to the end of the file.  All readers (decode, memory map, duration probe) take them."""
+    rng = np.random.default_rng(5)
+    pcm = rng.integers(-20000, 20000, size=(3000, 2), dtype=np.int16)
+    payload = pcm.tobytes()
+    fmt = struct.pack("<HHIIHH", 1, 2, 16000, 64000, 4, 16)
+    ds64 = b"" if magic == b"RIFF" else b"ds64" + struct.pack("<IQQQI", 28, 0, len(payload), 3000, 0)
+    p = tmp_path / "big.wav"
+    p.write_bytes(magic + struct.pack("<I", 0xFFFFFFFF) + b"WAVE" + ds64 + b"fmt " + struct.pack("<I", 16) + fmt +
+                  b"data" + struct.pack("<I", 0xFFFFFFFF) + payload + trailer)
+    x, rate = audio.read_audio(p)
+    assert rate == 16000 and np.array_equal(x, pcm.astype(np.float32) / 32768.0)
+    mapped = audio.map_wav_pcm16(p)
+    assert mapped is not None and np.array_equal(mapped[0].reshape(-1, 2), pcm) and mapped[1:] == (2, 16000)
+    assert audio.audio_duration(p) == 3000 / 16000.0
+    assert np.array_equal(audio.load_audio_16k(p), pcm.astype(np.float32).mean(axis=1) / 32768.0)
+
+
 def test_compressed_formats_raise(tmp_path):
     p = tmp_path / "a.mp3"
     p.write_bytes(b"ID3....")
