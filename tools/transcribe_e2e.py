@@ -4,6 +4,8 @@ disk, end to end - file read, decode, chunk plan, device path, CTC stage, segmen
 loading shown separately.
 Usage: transcribe_e2e.py [hours [rate [channels [width]]]]   WAV of synthetic noise + tone (width 2 or 3 bytes)
        transcribe_e2e.py flac [repeats]               FLAC made of the reference upload's frames (tests/flac_tools.py)
+       transcribe_e2e.py rf64 [hours]                 RF64 WAV beyond 4 GB: 48 kHz 16-bit stereo (9.5 h = 6.6 GB), one minute
+                                                      of noise + tone repeated
        transcribe_e2e.py mp3 [repeats]                MP3 made of the audio frames of the reference's demo recording
                                                       (40 s at 44.1 kHz joint stereo per repeat; the frame at each
                                                       join finds another bit reservoir than it was written for)"""
@@ -60,7 +62,30 @@ def write_mp3(repeats: int):
     return path, total / rate / 3600.0
 
 
-if len(sys.argv) > 1 and sys.argv[1] == "mp3":
+def write_rf64(hours: float) -> str:
+    import struct
+    rate, channels = 48000, 2
+    minutes = int(round(hours * 60))
+    rng = np.random.default_rng(0)
+    t = np.arange(rate * 60, dtype=np.float32)
+    mono = (3000 * rng.standard_normal(t.size).astype(np.float32) + 6000 * np.sin(t * (2 * np.pi * 440 / rate))).astype("<i2")
+    block = np.repeat(mono, channels).tobytes()
+    data_bytes = len(block) * minutes
+    path = os.path.join(tempfile.gettempdir(), "oasr_e2e_rf64.wav")
+    with open(path, "wb") as f:
+        f.write(b"RF64" + struct.pack("<I", 0xFFFFFFFF) + b"WAVE")
+        f.write(b"ds64" + struct.pack("<IQQQI", 28, 72 + data_bytes, data_bytes, data_bytes // (2 * channels), 0))
+        f.write(b"fmt " + struct.pack("<IHHIIHH", 16, 1, channels, rate, rate * channels * 2, channels * 2, 16))
+        f.write(b"data" + struct.pack("<I", 0xFFFFFFFF))
+        for _ in range(minutes):
+            f.write(block)
+    return path
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "rf64":
+    hours = float(sys.argv[2]) if len(sys.argv) > 2 else 9.5
+    path = write_rf64(hours)
+elif len(sys.argv) > 1 and sys.argv[1] == "mp3":
     path, hours = write_mp3(int(sys.argv[2]) if len(sys.argv) > 2 else 180)
 elif len(sys.argv) > 1 and sys.argv[1] == "flac":
     path, hours = write_flac(int(sys.argv[2]) if len(sys.argv) > 2 else 400)
@@ -89,4 +114,16 @@ for rep in range(3):
     dt = time.perf_counter() - t0
     print("run %d: %.2f h -> %.3f s wall (audio loading %.3f s) = RTF %.0fx; %d segments" %
           (rep, hours, dt, load_s[0], hours * 3600 / dt, len(res.segments)), flush=True)
+if len(sys.argv) > 1 and sys.argv[1] == "rf64":
+    # the signal repeats every minute: a chunk's text must equal that of the chunk one minute earlier, also where the
+    # file's byte offsets no longer fit 32 bits (past 6.2 h)
+    texts = [seg.text for seg in res.segments]
+    late = [i for i, seg in enumerate(res.segments) if seg.start * 48000 * 4 > 2 ** 32]
+    # (the first and the last chunk see the silence outside the file through the rate converter's filter)
+    differ = [i for i in range(3, len(texts) - 1) if texts[i] != texts[i - 2]]
+    print("texts repeat with the one-minute period over chunks 1 .. %d (%d of them past the 4 GiB offset): %s %s; "
+          "distinct non-empty texts among them: %d" % (len(texts) - 2, len(late), not differ, differ[:10],
+                                                        len(set(texts[1:-1]))))
+    if differ or not all(texts):
+        sys.exit(1)
 os.remove(path)
