@@ -41,6 +41,7 @@ WINDOW_D = _h * np.where((np.arange(512) >> 6) & 1, -1.0, 1.0)     # the standar
 _CI = np.array([-0.6, -0.535, -0.33, -0.185, -0.095, -0.041, -0.0142, -0.0037])
 CS, CA = 1 / np.sqrt(1 + _CI ** 2), _CI / np.sqrt(1 + _CI ** 2)
 
+LSF_PARTS = np.array(_table("kLsfPartitions[6][3][4]")).reshape(6, 3, 4).tolist()   # [rule][long | short | mixed]
 LINBITS = {16: 1, 17: 2, 18: 3, 19: 4, 20: 6, 21: 8, 22: 10, 23: 13, 24: 4, 25: 5, 26: 6, 27: 7, 28: 8, 29: 9, 30: 11, 31: 13}
 SLEN = [(0, 0), (0, 1), (0, 2), (0, 3), (3, 0), (1, 1), (1, 2), (1, 3), (2, 1), (2, 2), (2, 3), (3, 1), (3, 2), (3, 3), (4, 2), (4, 3)]
 
@@ -408,10 +409,21 @@ def encode(pcm, rate, *, seed=0, ms=False, crc=False, block_types=None, peak_is=
                                         scfsi[c][k] = 1
                                         scf[edges[k]:edges[k + 1]] = prev_scf[c][edges[k]:edges[k + 1]]
                     else:
-                        sl = [int(rng.integers(5)), int(rng.integers(5)), int(rng.integers(4)), int(rng.integers(4))]
+                        # the second standard's three ways of stating the scale-factor widths (the third implies preflag)
+                        rule = int(rng.integers(3))
+                        if rule == 0:
+                            sl = [int(rng.integers(5)), int(rng.integers(5)), int(rng.integers(4)), int(rng.integers(4))]
+                            gi["scalefac_compress"] = ((sl[0] * 5 + sl[1]) << 4) | (sl[2] << 2) | sl[3]
+                        elif rule == 1:
+                            sl = [int(rng.integers(5)), int(rng.integers(5)), int(rng.integers(4)), 0]
+                            gi["scalefac_compress"] = 400 + (((sl[0] * 5 + sl[1]) << 2) | sl[2])
+                        else:
+                            sl = [int(rng.integers(4)), int(rng.integers(3)), 0, 0]
+                            gi["scalefac_compress"] = 500 + sl[0] * 3 + sl[1]
+                            gi["preflag"] = 1
                         gi["slen"] = sl
-                        gi["scalefac_compress"] = ((sl[0] * 5 + sl[1]) << 4) | (sl[2] << 2) | sl[3]
-                        parts = [6, 5, 5, 5] if bt != 2 else [6, 9, 9, 9] if mix else [9, 9, 9, 9]
+                        parts = LSF_PARTS[rule][0 if bt != 2 else 2 if mix else 1]
+                        gi["parts"] = parts
                         i = 0
                         for k in range(4):
                             scf[i:i + parts[k]] = rng.integers(0, 1 << sl[k], parts[k])

@@ -37,6 +37,13 @@ def test_code_books_are_complete_prefix_codes_and_the_include_file_is_theirs():
         assert nodes == gen.build_tree(n), n
 
 
+def test_second_standard_partition_table_is_consistent():
+    """Every way of splitting the scale factors into four width classes must cover the same bands: 21 for long granules,
+    36 for short ones, 33 for mixed ones (6 long + 27 short)."""
+    for rule in mt.LSF_PARTS:
+        assert [sum(row) for row in rule] == [21, 36, 33], rule
+
+
 @pytest.fixture(scope="module")
 def demo(golden_dir):
     x, rate, diag = audio.read_mp3(golden_dir / "reference_demo_40s.mp3", diagnostics=True)
