@@ -102,3 +102,54 @@ def test_result_to_data_from_public_segments():
     assert data["segments"][0]["words"] == [{"word": "hi", "start": 0.2, "end": 0.6}] and data["segments"][1]["words"] == []
     assert "hi" in X.build_textgrid(data) and set(X.EXPORTERS) == {"eaf", "textgrid", "txt", "srt", "json"}
     assert X.build_srt(data).startswith("1\n00:00:00,000 --> 00:00:01,500\nhi\n")
+
+
+def test_real_annotation_data_round_trips_through_every_format(golden_dir):
+    """The reference's own annotation of its demo recording (ref:samuel_lisu.eaf as data: 36 intervals, 314 words,
+    text in Arabic, Tibetan, Chinese and Latin script; tests/golden/reference_lisu_annotation.json, made by
+    oracle/gen_eaf_fixture.py) through all five writers and read back: every time (whole milliseconds) and every
+    text survives.  This checks the writers against themselves on real data, not against the reference's writer."""
+    import json
+    import re
+    import xml.etree.ElementTree as ET
+
+    src = json.loads((golden_dir / "reference_lisu_annotation.json").read_text(encoding="utf-8"))["segments"]
+    data = {"audio_url": "Samuel Speaking Lisu.mp3", "summary": None, "detected_languages": [],
+            "segments": [{"start": s["start_ms"] / 1000.0, "end": s["end_ms"] / 1000.0, "speaker": s["speaker"],
+                          "text": s["text"],
+                          "words": [{"word": w["word"], "start": w["start_ms"] / 1000.0, "end": w["end_ms"] / 1000.0}
+                                    for w in s["words"]]} for s in src]}
+    want = [(s["start_ms"], s["end_ms"], s["text"]) for s in src]
+    assert len(want) == 36 and any(ord(c) > 0x4E00 for _, _, t in want for c in t)
+
+    root = ET.fromstring(X.build_eaf(data).encode("utf-8"))
+    slot = {t.get("TIME_SLOT_ID"): int(t.get("TIME_VALUE")) for t in root.iter("TIME_SLOT")}
+    tiers = list(root.iter("TIER"))
+    assert [t.get("TIER_ID") for t in tiers] == ["SPEAKER_00"]
+    got = [(slot[a.get("TIME_SLOT_REF1")], slot[a.get("TIME_SLOT_REF2")], a.findtext("ANNOTATION_VALUE"))
+           for a in tiers[0].iter("ALIGNABLE_ANNOTATION")]
+    assert got == want
+
+    def ms(stamp):
+        h, m, rest = stamp.split(":")
+        sec, milli = rest.split(",")
+        return ((int(h) * 60 + int(m)) * 60 + int(sec)) * 1000 + int(milli)
+    blocks = X.build_srt(data).strip().split("\n\n")
+    got = []
+    for i, b in enumerate(blocks):
+        idx, times, text = b.split("\n", 2)
+        a, z = times.split(" --> ")
+        assert int(idx) == i + 1
+        got.append((ms(a), ms(z), text))
+    assert got == want                                   # one speaker: no prefix
+
+    tg = X.build_textgrid(data)
+    spoken = [(round(float(a) * 1000), round(float(z) * 1000), t.replace('""', '"'))
+              for a, z, t in re.findall(r'xmin = ([0-9.]+) \n\s+xmax = ([0-9.]+)\n\s+text = "((?:[^"]|"")*)"', tg) if t]
+    words = [(w["start_ms"], w["end_ms"], w["word"]) for s in src for w in s["words"]]
+    assert len(words) == 314 and spoken == words          # segments that have words are written word by word
+
+    assert json.loads(X.build_json(data)) == data
+    txt = X.build_plain_text(data)
+    assert all(t in txt for _, _, t in want) and txt.count("[SPEAKER_00]") == 1
+
