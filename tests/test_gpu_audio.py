@@ -167,6 +167,31 @@ def test_long_mp3_in_segments_equals_the_one_pass_path(golden_dir, chunk_seconds
     assert Pipeline(model="GTINY", batch_size=32).gemini._encode_streamed(path, False) is None     # too short to split
 
 
+@pytest.mark.parametrize("rate", [8000, 11025, 16000, 22050, 32000, 48000])
+def test_segments_equal_one_pass_at_every_rate_ratio(tmp_path, rate):
+    """The segment path's arithmetic (a segment starts on a whole period of the rate converter and carries the filter's
+    reach on both sides) at the other conversion ratios: 2/1, 640/441, 1/1, 320/441, 1/2, 1/3.  Files from the test
+    encoder (tests/mp3_tools.py), 9 s, one-second chunks, segments of four chunks."""
+    import mp3_tools as mt
+    from omnilingual_asr import Pipeline
+
+    rng = np.random.default_rng(rate)
+    spf = 576 if rate < 32000 else 1152
+    frames = 9 * rate // spf + 1
+    pcm = rng.standard_normal((frames * spf, 1))
+    pcm = np.cumsum(pcm, axis=0) * 0.02 + pcm * 0.1
+    data, _ = mt.encode(pcm / np.abs(pcm).max() * 0.5, rate, peak_is=[7, 15], seed=rate)
+    path = tmp_path / "r.mp3"
+    path.write_bytes(data)
+    pipe = Pipeline(model="GTINY", seed=4, batch_size=2, chunk_seconds=1.0, min_chunking_seconds=1.0).gemini
+    streamed = pipe._encode_streamed(path, True)
+    whole = pipe._encode_file(pipe._load_audio(path), True)
+    assert streamed is not None and len(streamed.segments) == len(whole.segments) >= 9
+    for a, b in zip(streamed.segments, whole.segments):
+        assert (a.start, a.end, a.text, a.words) == (b.start, b.end, b.text, b.words)
+    assert any(s.text for s in whole.segments)
+
+
 def test_host_only_call_before_the_engine_leaves_the_device_usable(golden_dir):
     """A host-only entry point (the FLAC decoder) used before any engine exists must not leave the process
     with a second HIP runtime: the library loader brings torch's in first.  Run in a child process, where
