@@ -295,6 +295,13 @@ class GeminiASRPipeline:
         self._fp8 = bool(fp8)
         self._engine = engine
         self._engine_lock = threading.Lock()   # one device stream: concurrent callers serialise here
+        self._per_thread = threading.local()   # diagnostics of the calling thread's last call
+
+    @property
+    def decoded_source_samples(self) -> int:
+        """Source samples the calling thread's last segmented (`_encode_streamed`) call decoded: its share of the
+        file under a process group, the rate converter's reach on both sides of every segment included."""
+        return getattr(self._per_thread, "decoded_source_samples", 0)
 
     # ---- engine ---------------------------------------------------------------------------------------
     @property
@@ -473,11 +480,11 @@ class GeminiASRPipeline:
 
             from concurrent.futures import ThreadPoolExecutor
             records: List[ChunkRecord] = []
-            self.decoded_source_samples = 0      # what this call decoded (a rank's share of the file, halos included)
+            decoded = [0]
             with ThreadPoolExecutor(max_workers=1, thread_name_prefix="oasr-decode") as pool:
                 def fetch(c0):
                     _, _, _, _, lo, hi = span(c0)
-                    self.decoded_source_samples += hi - lo
+                    decoded[0] += hi - lo
                     return stream.read_mono(lo, hi - lo)
                 pending = pool.submit(fetch, firsts[0]) if firsts else None
                 for i, c0 in enumerate(firsts):
@@ -494,6 +501,7 @@ class GeminiASRPipeline:
                     local = bounds[c0:c1] - a_out
                     for r in self._encode_chunks(signal, local, first_idx=c0):
                         records.append(replace(r, start_sample=r.start_sample + a_out, end_sample=r.end_sample + a_out))
+            self._per_thread.decoded_source_samples = decoded[0]
         if self.process_group is not None:
             records = _dist.exchange_records(records, bounds, self.process_group)
         if not records:
