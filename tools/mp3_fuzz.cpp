@@ -8,6 +8,8 @@
 //   g++ -O1 -g -fsanitize=address -no-pie tools/mp3_fuzz.cpp /tmp/mp3_asan.o -o /tmp/mp3_fuzz \
 //         -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib -lpthread
 //   ASAN_OPTIONS=detect_leaks=0 /tmp/mp3_fuzz tests/golden/reference_demo_40s.mp3 600
+// With UndefinedBehaviorSanitizer as well: add `-Xarch_host -fsanitize=undefined -Xarch_host -fno-sanitize-recover=undefined`
+// to the hipcc line and link with /opt/rocm/lib/llvm/bin/clang++ -fsanitize=address,undefined (its runtime, not gcc's).
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
