@@ -85,6 +85,8 @@ def read_wav(path) -> tuple[np.ndarray, int]:
         tag = struct.unpack_from("<H", fmt, 24)[0]
     if channels < 1 or block < 1:
         raise UnsupportedAudioError("WAV header declares no channels")
+    if tag in (1, 3, 6, 7) and block != channels * ((bits + 7) // 8):
+        raise UnsupportedAudioError("WAV header: %d bytes per frame for %d channel(s) of %d bits" % (block, channels, bits))
     n = len(payload) // block
     raw = payload[: n * block]
     if tag == 1:
@@ -242,6 +244,24 @@ def audio_duration(path) -> float:
     raise UnsupportedAudioError("no duration in the header")
 
 
+MAX_CONVERSION_TERM = 200_000   # largest numerator / denominator of a rate ratio the converter designs a filter for
+
+
+def conversion_ratio(rate_in: int, rate_out: int = TARGET_RATE) -> tuple[int, int]:
+    """(up, down) of rate_out / rate_in in lowest terms.  The low-pass has 20 * max(up, down) + 1 taps, so a header
+    that states an absurd rate (a damaged or hostile file: 1.1 GHz, or a value sharing no factor with the target)
+    would ask for a filter of billions of taps; every real rate (8 kHz .. 768 kHz, the odd 44 056 and 47 999
+    included) stays far below the bound."""
+    rate_in = int(rate_in)
+    if not 100 <= rate_in <= 4_000_000:
+        raise UnsupportedAudioError("sample rate %d Hz is outside 100 Hz .. 4 MHz" % rate_in)
+    fr = Fraction(int(rate_out), rate_in)
+    if max(fr.numerator, fr.denominator) > MAX_CONVERSION_TERM:
+        raise UnsupportedAudioError("sample rate %d Hz cannot be converted to %d Hz (ratio %d/%d)"
+                                    % (rate_in, rate_out, fr.numerator, fr.denominator))
+    return fr.numerator, fr.denominator
+
+
 def resample_filter(up: int, down: int, half_width: int = 10, beta: float = 5.0) -> np.ndarray:
     """Kaiser-windowed sinc low-pass at the up-sampled rate, cut-off at the lower Nyquist, unity
     DC gain times `up`; length 2 * half_width * max(up, down) + 1 (zero phase)."""
@@ -255,8 +275,7 @@ def resample_filter(up: int, down: int, half_width: int = 10, beta: float = 5.0)
 def polyphase_branches(rate_in: int, rate_out: int = TARGET_RATE):
     """(up, down, half, hp) with hp[p, j] = h[p + j * up], float64 [up, taps]: the table both the host
     resampler below and the device kernel (`oasr_resample_poly`) read."""
-    fr = Fraction(rate_out, rate_in)
-    up, down = fr.numerator, fr.denominator
+    up, down = conversion_ratio(rate_in, rate_out)
     h = resample_filter(up, down)
     half = (len(h) - 1) // 2
     taps = -(-len(h) // up)
@@ -272,8 +291,7 @@ def resample_poly(x: np.ndarray, rate_in: int, rate_out: int = TARGET_RATE) -> n
     ceil(len(x) * up / down).  float64 accumulate, float32 result."""
     if rate_in == rate_out:
         return np.asarray(x, dtype=np.float32)
-    fr = Fraction(rate_out, rate_in)
-    up, down = fr.numerator, fr.denominator
+    up, down = conversion_ratio(rate_in, rate_out)
     h = resample_filter(up, down)
     half = (len(h) - 1) // 2
     x = np.asarray(x, dtype=np.float64)
@@ -372,6 +390,8 @@ def read_flac(path) -> tuple[np.ndarray, int]:
     L = _hip.lib()
     _hip.check(L.oasr_flac_info(buf.ctypes.data, buf.size, C.byref(rate), C.byref(channels), C.byref(bits),
                                 C.byref(total), None), "oasr_flac_info")
+    if total.value > buf.size * 8192:        # (a frame of 65 535 constant samples still takes about ten bytes)
+        raise UnsupportedAudioError("FLAC header declares %d samples, more than %d bytes can hold" % (total.value, buf.size))
     out = np.empty((max(total.value, 1), channels.value), dtype=np.int32)
     written = C.c_int64()
     _hip.check(L.oasr_flac_decode(buf.ctypes.data, buf.size, out.ctypes.data, out.shape[0], C.byref(written)),
@@ -397,6 +417,8 @@ def read_flac_pcm(path):
     L = _hip.lib()
     _hip.check(L.oasr_flac_info(buf.ctypes.data, buf.size, C.byref(rate), C.byref(channels), C.byref(bits),
                                 C.byref(total), None), "oasr_flac_info")
+    if total.value > buf.size * 8192:        # (a frame of 65 535 constant samples still takes about ten bytes)
+        raise UnsupportedAudioError("FLAC header declares %d samples, more than %d bytes can hold" % (total.value, buf.size))
     narrow = bits.value <= 16
     out = np.empty((max(total.value, 1) * channels.value,), dtype=np.int16 if narrow else np.int32)
     written = C.c_int64()

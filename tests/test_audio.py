@@ -129,6 +129,38 @@ def test_wav_beyond_four_gigabytes_forms(tmp_path, magic, trailer):
     assert np.array_equal(audio.load_audio_16k(p), pcm.astype(np.float32).mean(axis=1) / 32768.0)
 
 
+def test_damaged_headers_are_refused_not_obeyed(tmp_path, golden_dir):
+    """A header may state anything.  An absurd sampling rate would make the rate converter design a filter of up to
+    billions of taps, a frame size that contradicts the channel count breaks the sample layout, a FLAC sample count
+    beyond what the file can hold asks for terabytes: each is refused with UnsupportedAudioError, at once."""
+    import time
+    pcm = np.zeros(4000, dtype="<i2").tobytes()
+    t0 = time.perf_counter()
+    for rate in (1_124_089_472, 47_999_999, 3, 0, 1_000_003):      # the last: prime, shares no factor with 16 000
+        p = tmp_path / "r.wav"
+        p.write_bytes(_wav_bytes(1, 16, 1, rate, pcm))
+        with pytest.raises(audio.UnsupportedAudioError):
+            audio.load_audio_16k(p)
+    for rate in (8000, 11025, 44056, 47999, 96000, 192000, 352800, 768000):   # real rates, the odd ones included
+        assert max(audio.conversion_ratio(rate)) <= audio.MAX_CONVERSION_TERM
+    p = tmp_path / "b.wav"
+    blob = bytearray(_wav_bytes(1, 16, 1, 16000, pcm))
+    struct.pack_into("<H", blob, blob.index(b"fmt ") + 8 + 12, 60)          # 60 bytes per frame for one 16-bit channel
+    p.write_bytes(bytes(blob))
+    with pytest.raises(audio.UnsupportedAudioError):
+        audio.read_wav(p)
+    flac = bytearray((golden_dir / "reference_upload.flac").read_bytes())
+    flac[21] |= 0x0F                                                        # top bits of the 36-bit sample count
+    flac[22] = 0xFF
+    p = tmp_path / "f.flac"
+    p.write_bytes(bytes(flac))
+    with pytest.raises(audio.UnsupportedAudioError):
+        audio.read_flac(p)
+    with pytest.raises(audio.UnsupportedAudioError):
+        audio.read_flac_pcm(p)
+    assert time.perf_counter() - t0 < 5.0
+
+
 def test_compressed_formats_raise(tmp_path):
     p = tmp_path / "a.mp3"
     p.write_bytes(b"ID3....")
