@@ -253,8 +253,8 @@ def conversion_ratio(rate_in: int, rate_out: int = TARGET_RATE) -> tuple[int, in
     would ask for a filter of billions of taps; every real rate (8 kHz .. 768 kHz, the odd 44 056 and 47 999
     included) stays far below the bound."""
     rate_in = int(rate_in)
-    if not 100 <= rate_in <= 4_000_000:
-        raise UnsupportedAudioError("sample rate %d Hz is outside 100 Hz .. 4 MHz" % rate_in)
+    if not 1000 <= rate_in <= 4_000_000:    # (below 1 kHz the converter would also inflate the file more than 16-fold)
+        raise UnsupportedAudioError("sample rate %d Hz is outside 1 kHz .. 4 MHz" % rate_in)
     fr = Fraction(int(rate_out), rate_in)
     if max(fr.numerator, fr.denominator) > MAX_CONVERSION_TERM:
         raise UnsupportedAudioError("sample rate %d Hz cannot be converted to %d Hz (ratio %d/%d)"

@@ -136,7 +136,7 @@ def test_damaged_headers_are_refused_not_obeyed(tmp_path, golden_dir):
     import time
     pcm = np.zeros(4000, dtype="<i2").tobytes()
     t0 = time.perf_counter()
-    for rate in (1_124_089_472, 47_999_999, 3, 0, 1_000_003):      # the last: prime, shares no factor with 16 000
+    for rate in (1_124_089_472, 47_999_999, 3, 0, 999, 1_000_003):      # the last: prime, shares no factor with 16 000
         p = tmp_path / "r.wav"
         p.write_bytes(_wav_bytes(1, 16, 1, rate, pcm))
         with pytest.raises(audio.UnsupportedAudioError):
