@@ -44,7 +44,8 @@ MAX_PARALLEL = 4                                                   # ref :395-39
 
 
 def _now_iso() -> str:
-    return datetime.now(timezone.utc).strftime("%Y-%m-%dT%H:%M:%SZ")
+    """UTC to the second with a 'Z' suffix: the `created_at` form of the reference's history entries (ref :63-64)."""
+    return datetime.now(timezone.utc).replace(microsecond=0, tzinfo=None).isoformat() + "Z"
 
 
 def parse_multipart(content_type: str, body: bytes) -> List[Tuple[str, Optional[str], bytes]]:
@@ -101,28 +102,31 @@ def create_app(pipeline=None, upload_dir: Optional[Path] = None, static_dir: Opt
         return entry
 
     def save_upload(filename: Optional[str], payload: bytes, dest: Path) -> Tuple[Path, str]:
-        if not filename:
-            raise HTTPException(status_code=400, detail="Missing file name.")
-        ext = Path(filename).suffix.lower()
-        if ext not in UPLOAD_EXT:
-            raise HTTPException(status_code=400, detail="Unsupported file type.")
-        out = dest / (uuid.uuid4().hex + ext)
-        out.write_bytes(payload)
-        return out, filename
+        """Stores an upload under a random name that keeps its extension; the two refusals and their texts are the
+        reference's (ref :98-108)."""
+        suffix = Path(filename).suffix.lower() if filename else None
+        problem = "Missing file name." if suffix is None else None if suffix in UPLOAD_EXT else "Unsupported file type."
+        if problem:
+            raise HTTPException(status_code=400, detail=problem)
+        stored = dest / (uuid.uuid4().hex + suffix)
+        stored.write_bytes(payload)
+        return stored, filename
 
     def safe_extract_zip(zip_path: Path, dest: Path) -> List[Tuple[Path, str]]:
-        found = []
+        """Unpacks an archive below `dest` and lists its audio files as (path, name inside the archive).  Members that
+        would land outside `dest` (absolute names, '..' components) are skipped, as the reference skips them (ref :80-95)."""
+        def inside(name: str) -> bool:
+            member = Path(name)
+            return not member.is_absolute() and ".." not in member.parts
+
         with zipfile.ZipFile(zip_path) as zf:
-            for info in zf.infolist():
-                member = Path(info.filename)
-                if info.is_dir() or ".." in member.parts or member.is_absolute():
-                    continue
-                target = dest / member
+            wanted = [info for info in zf.infolist() if not info.is_dir() and inside(info.filename)]
+            for info in wanted:
+                target = dest / info.filename
                 target.parent.mkdir(parents=True, exist_ok=True)
                 target.write_bytes(zf.read(info))
-                if target.suffix.lower() in AUDIO_EXT:
-                    found.append((target, member.as_posix()))
-        return found
+        return [(dest / info.filename, Path(info.filename).as_posix()) for info in wanted
+                if Path(info.filename).suffix.lower() in AUDIO_EXT]
 
     def run(audio_path: Path, **kw) -> Dict[str, Any]:
         pipe = get_pipeline()
