@@ -158,7 +158,7 @@ def test_damaged_headers_are_refused_not_obeyed(tmp_path, golden_dir):
         audio.read_flac(p)
     with pytest.raises(audio.UnsupportedAudioError):
         audio.read_flac_pcm(p)
-    assert time.perf_counter() - t0 < 5.0
+    assert time.perf_counter() - t0 < 15.0          # (obeying the first header alone took 36 s, or the machine's memory)
 
 
 def test_compressed_formats_raise(tmp_path):
