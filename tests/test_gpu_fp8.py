@@ -145,9 +145,15 @@ def test_gemm_fp8_rejects_bad_shapes():
 
 
 def test_encoder_fp8_matches_fake_quant_oracle():
-    """GTINY with fp8 projections against the oracle that quantises the same operands to e4m3: what
-    is left is bf16 activation rounding, as in the bf16 mode, so the same tolerance applies; the fp8
-    result must also differ from the bf16 one (the mode is really on)."""
+    """GTINY (2 blocks) with fp8 projections, end to end, against the oracle that rounds where the device
+    rounds and quantises the same rows to e4m3 (`device_rounding=True, fp8=True`), and against the plain
+    float32 oracle.  End to end the distance to the emulation cannot be small: an e4m3 rounding turns a
+    difference of relative size e into ~sqrt(e * 2^-3), so two correct implementations sit at about half
+    the quantisation noise after a block whatever their summation orders (measured 1.6e-2 after one
+    block, 2.3e-2 after two, at every width) — the sharp check of the fp8 kernels is the operator-by-operator
+    one in tests/test_gpu_stages.py (<= 6e-4).  Stated bounds here: rel-L2 <= 3e-2 against the emulation,
+    <= 5e-2 against float32 (measured 3.6e-2: the cost of e4m3 itself), and the result must differ from
+    the bf16 path's (the mode is really on)."""
     from omnilingual_asr.engine_hip import HipEngine
     from omnilingual_asr.weights import GEOMETRIES, init_random_weights
     from oracle import conformer as OC
@@ -161,8 +167,10 @@ def test_encoder_fp8_matches_fake_quant_oracle():
     n_valid = [64000, 41000]
     feats, lens = OL.features_batch(pcm.numpy(), n_valid)
     enc_w = {k: v for k, v in w.items() if not k.startswith("ctc_")}
-    ref8 = OC.forward(torch.from_numpy(feats), torch.from_numpy(lens), enc_w, og, fp8=True)
-    ref16 = OC.forward(torch.from_numpy(feats), torch.from_numpy(lens), enc_w, og)
+    ft, lt = torch.from_numpy(feats), torch.from_numpy(lens)
+    ref8 = OC.forward(ft, lt, enc_w, og, fp8=True, device_rounding=True)
+    ref16 = OC.forward(ft, lt, enc_w, og)
+    emu16 = OC.forward(ft, lt, enc_w, og, device_rounding=True)
     eng8 = HipEngine("GTINY", weights=w, fp8=True)
     h8, l8 = eng8.encode_batch(pcm, n_valid)
     h8 = h8.cpu()
@@ -171,18 +179,20 @@ def test_encoder_fp8_matches_fake_quant_oracle():
     rel = lambda a, b: float((a - b).norm() / b.norm())
     for i, n in enumerate(lens):
         assert int(l8[i]) == int(n)
-        assert rel(h8[i, :n], ref8[i, :n]) <= 3e-2            # vs the emulation of the same quantisation
-        assert rel(h8[i, :n], ref16[i, :n]) <= 1.5e-1           # stated fp8 tolerance vs the float32 oracle
-        assert rel(h8[i, :n], h16[i, :n]) > 5e-3               # and not the bf16 path
+        assert rel(h8[i, :n], ref8[i, :n]) <= 3e-2            # vs the emulation of the same roundings
+        assert rel(h8[i, :n], ref16[i, :n]) <= 5e-2           # stated fp8 tolerance vs the float32 oracle
+        assert rel(h8[i, :n], h16[i, :n]) > 5e-3              # and not the bf16 path
+        assert rel(h16[i, :n], emu16[i, :n]) <= 4e-3          # bf16 path vs its emulation (measured 2.0e-3)
     assert torch.isfinite(h8).all()
 
 
 def test_encoder_block_at_the_7b_width_bf16_and_fp8():
     """One block of the 7B geometry (d = 4096, ffn 16384, 32 heads x 128) on a short ragged batch, so the
     CPU oracle stays cheap: bf16 against the float32 oracle (rel-L2 <= 2e-2, max abs <= 0.15) and fp8
-    against the oracle emulating the same quantisation (rel-L2 <= 3e-2; <= 1.5e-1 against float32).  At
-    this width the convolution module runs its unfused form (convolution -> float32 rows -> LayerNorm +
-    Swish), which this test is the cover for."""
+    against the oracle emulating the same roundings (rel-L2 <= 2.2e-2, measured 1.6e-2; <= 4e-2 against
+    float32, measured 3.0e-2).  At this width the convolution module runs its unfused form (convolution ->
+    float32 rows -> LayerNorm + Swish), which this test covers end to end; all 18 blocks are in
+    tests/test_gpu_depth.py."""
     import dataclasses
     from omnilingual_asr.engine_hip import HipEngine
     from omnilingual_asr.weights import GEOMETRIES, init_random_weights
@@ -200,7 +210,7 @@ def test_encoder_block_at_the_7b_width_bf16_and_fp8():
     enc_w = {k: v for k, v in w.items() if not k.startswith("ctc_")}
     ft, lt = torch.from_numpy(feats), torch.from_numpy(lens)
     ref16 = OC.forward(ft, lt, enc_w, og)
-    ref8 = OC.forward(ft, lt, enc_w, og, fp8=True)
+    ref8 = OC.forward(ft, lt, enc_w, og, fp8=True, device_rounding=True)
     rel = lambda a, b: float((a - b).norm() / b.norm())
     h16, l16 = HipEngine(g, weights=w).encode_batch(pcm, n_valid)
     h16 = h16.cpu()
@@ -210,8 +220,8 @@ def test_encoder_block_at_the_7b_width_bf16_and_fp8():
         assert int(l16[i]) == int(n)
         assert rel(h16[i, :n], ref16[i, :n]) <= 2e-2
         assert float((h16[i, :n] - ref16[i, :n]).abs().max()) <= 0.15
-        assert rel(h8[i, :n], ref8[i, :n]) <= 3e-2
-        assert rel(h8[i, :n], ref16[i, :n]) <= 1.5e-1
+        assert rel(h8[i, :n], ref8[i, :n]) <= 2.2e-2
+        assert rel(h8[i, :n], ref16[i, :n]) <= 4e-2
         assert rel(h8[i, :n], h16[i, :n]) > 5e-3
 
 

@@ -94,3 +94,41 @@ def test_encoder_matches_standin_at_the_device_width(golden_dir):
         want = torch.from_numpy(z[f"hidden_{k}"])
         for b, n in enumerate(lens.tolist()):
             torch.testing.assert_close(per[k][b, :n], want[b, :n], atol=2e-5, rtol=1e-5)
+
+
+def test_device_rounding_mode_of_the_encoder_oracle_stays_next_to_the_plain_forward():
+    """`forward(device_rounding=True)` restates where the device rounds to 16 bits (and, with fp8, which rows it
+    quantises): it must stay within bfloat16 / e4m3 noise of the plain float32 forward, and its attention walk
+    over key tiles with a lazily raised maximum must give the plain softmax when nothing is rounded."""
+    import torch
+    from omnilingual_asr.weights import GEOMETRIES, init_random_weights
+    from oracle import conformer as OC
+
+    g = GEOMETRIES["GTINY"]
+    og = OC.Geometry(name=g.name, d_model=g.d_model, ffn_dim=g.ffn_dim, n_heads=g.n_heads, n_layers=g.n_layers)
+    w = {k: v for k, v in init_random_weights(g, 21).items() if not k.startswith("ctc_")}
+    gen = torch.Generator().manual_seed(3)
+    feats = torch.randn((2, 150, 160), generator=gen)
+    lens = torch.tensor([150, 77])
+    plain = OC.forward(feats, lens, w, og)
+    emu = OC.forward(feats, lens, w, og, device_rounding=True)
+    emu8 = OC.forward(feats, lens, w, og, device_rounding=True, fp8=True)
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    for i, n in enumerate(lens):
+        assert 5e-4 < rel(emu[i, :n], plain[i, :n]) < 8e-3
+        assert 1e-2 < rel(emu8[i, :n], plain[i, :n]) < 6e-2
+    # the tiled softmax alone (no rounding: float64, identity rounding) equals the plain one
+    keep, keep16 = OC._r, OC._r16
+    OC._r = OC._r16 = lambda t: t
+    try:
+        OC._DEV = True
+        lw = {k: v.double() for k, v in w["layers"][0].items()}
+        x = torch.randn((2, 150, g.d_model), generator=gen, dtype=torch.float64)
+        tiled = OC.attention(x, lens, lw, og)
+        OC._DEV = False
+        direct = OC.attention(x, lens, lw, og)
+    finally:
+        OC._DEV = False
+        OC._r, OC._r16 = keep, keep16
+    for i, n in enumerate(lens):
+        torch.testing.assert_close(tiled[i, :n], direct[i, :n], atol=1e-9, rtol=1e-9)
