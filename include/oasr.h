@@ -236,7 +236,7 @@ typedef enum oasr_epilogue {
 } oasr_epilogue;
 
 /* C[m][n] = epilogue(sum_k A[m][k] * W[n][k]).  A bf16 [m][k], W bf16 [n][k]; m, n multiples of
- * 256, k a multiple of 64; bias float32[n] or NULL. */
+ * 256, k a multiple of 32; bias float32[n] or NULL. */
 int oasr_gemm_bf16(const uint16_t* a, const uint16_t* w, const float* bias, const float* resid,
                    void* c, int64_t m, int64_t n, int64_t k, float alpha, int32_t epilogue,
                    void* stream);
@@ -278,6 +278,15 @@ int oasr_flac_decode(const uint8_t* data, int64_t size, int32_t* out, int64_t ca
                      int64_t* written_per_channel);
 int oasr_flac_decode16(const uint8_t* data, int64_t size, int16_t* out, int64_t capacity_per_channel,
                        int64_t* written_per_channel);
+/* Samples [first, first + count) per channel of a stream whose header states its length, interleaved into
+ * out[0 .. count * channels): int16 scaled to 16 bits (out_bits 16, streams of at most 16 bits) or int32 at the
+ * stream's depth (out_bits 32) - the values oasr_flac_decode16 / oasr_flac_decode write at those positions.  Only
+ * the frames that cover the range are decoded (found from a byte position guessed by proportion and confirmed by
+ * both CRCs and the next frame's sample number); long ranges are split over host threads.  This is what lets a
+ * rank of a multi-GPU job decode its own shard of chunks and nothing else (the reference cuts its chunks out of
+ * the file with ffmpeg -ss/-t, ref gemini_pipeline.py:273-285). */
+int oasr_flac_decode_range(const uint8_t* data, int64_t size, int64_t first, int64_t count, void* out,
+                           int32_t out_bits);
 
 /* MPEG audio Layer III (MP3) decode on the host: the format of both demo recordings the reference ships and the first
  * upload type it lists (ref gemini_pipeline.py:106-118 MIME table, workflows/wav2elan_web/app.py:76-77; the reference

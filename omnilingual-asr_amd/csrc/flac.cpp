@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -375,17 +376,18 @@ struct Sink {
     int shift = 0;
     explicit operator bool() const { return o32 || o16; }
 };
-static void emit(const FrameScratch& fs, int nch, int64_t take, const Sink& sk, int64_t at) {
+// samples [skip, skip + take) of the frame go to sample positions at .. at + take of the output
+static void emit(const FrameScratch& fs, int nch, int64_t take, const Sink& sk, int64_t at, int64_t skip = 0) {
     if (sk.o16) {
         int16_t* dst = sk.o16 + at * nch;
         for (int c = 0; c < nch; ++c) {
-            const int64_t* src = fs.ch[c].data();
+            const int64_t* src = fs.ch[c].data() + skip;
             for (int64_t i = 0; i < take; ++i) dst[i * nch + c] = (int16_t)(src[i] << sk.shift);
         }
     } else {
         int32_t* dst = sk.o32 + at * nch;
         for (int c = 0; c < nch; ++c) {
-            const int64_t* src = fs.ch[c].data();
+            const int64_t* src = fs.ch[c].data() + skip;
             for (int64_t i = 0; i < take; ++i) dst[i * nch + c] = (int32_t)src[i];
         }
     }
@@ -502,6 +504,108 @@ static int64_t decode_parallel(const uint8_t* d, size_t n, const StreamInfo& si,
     return si.total;
 }
 
+// Samples [first, first + count) of the stream into out[0 .. count): frames are self-contained, so only the
+// frames that cover the range are decoded.  The frame that holds `first` is found from a byte position guessed
+// by proportion (the coded sample number in every frame header says where a candidate lies): a candidate is a
+// position where a whole frame decodes (sync code, header CRC-8, subframes, CRC-16) and the next frame follows it
+// sample for sample; if the first candidate found already lies past `first`, the search restarts further back.
+// Returns OASR_OK or a negative status (error text set).
+static int decode_range_one(const uint8_t* d, size_t n, const StreamInfo& si, const Sink& out, int64_t first, int64_t count) {
+    if (count <= 0) return OASR_OK;
+    const size_t begin = si.audio_start;
+    const int64_t last = first + count;
+    FrameScratch fs;
+    size_t guess = begin + (size_t)((double)(n - begin) * ((double)first / (double)si.total));
+    size_t back = 1 << 16;
+    for (;;) {
+        size_t pos = guess > begin + back ? guess - back : begin;
+        const bool from_start = pos == begin;
+        int blocksize = 0, nch = 0;
+        int64_t f0 = 0;
+        size_t len = 0;
+        for (; pos + 2 <= n; ++pos) {
+            if (d[pos] != 0xFF || (d[pos + 1] & 0xFE) != 0xF8) continue;
+            len = decode_frame(d, n, pos, si, fs, blocksize, f0, nch, nullptr);
+            if (!len) continue;
+            if (f0 + blocksize >= si.total) break;          // the stream's last frame: nothing to chain to
+            // a chance match inside a frame's data would not be followed by a frame that continues it
+            FrameScratch probe;
+            int bs2 = 0, nch2 = 0;
+            int64_t f2 = 0;
+            if (decode_frame(d, n, pos + len, si, probe, bs2, f2, nch2, nullptr) && f2 == f0 + blocksize) break;
+            len = 0;
+        }
+        if (!len && !from_start) {       // the guess lay inside the stream's last frame(s): look further back
+            back *= 4;
+            continue;
+        }
+        if (!len) {
+            set_error("flac: no frame found for sample %lld", (long long)first);
+            return OASR_EINVAL;
+        }
+        if (f0 > first) {
+            if (from_start) {
+                set_error("flac: the stream starts at sample %lld, after the requested %lld", (long long)f0, (long long)first);
+                return OASR_EINVAL;
+            }
+            back *= 4;
+            continue;
+        }
+        // decode forward from here
+        int64_t at = f0;
+        for (;;) {
+            const int64_t f_end = f0 + blocksize;
+            const int64_t lo = f0 > first ? f0 : first, hi = f_end < last ? f_end : last;
+            if (hi > lo) emit(fs, nch, hi - lo, out, lo - first, lo - f0);
+            at = f_end;
+            if (at >= last) return OASR_OK;
+            pos += len;
+            const char* why = "";
+            len = decode_frame(d, n, pos, si, fs, blocksize, f0, nch, &why);
+            if (!len) {
+                set_error("flac: %s at byte %zu", why, pos);
+                return OASR_EINVAL;
+            }
+            if (f0 != at) {
+                set_error("flac: frame at byte %zu starts at sample %lld, expected %lld", pos, (long long)f0, (long long)at);
+                return OASR_EINVAL;
+            }
+        }
+    }
+}
+
+// The range cut into equal parts for several threads (each finds its own first frame).
+static int decode_range(const uint8_t* d, size_t n, const StreamInfo& si, const Sink& out, int64_t first, int64_t count, int threads) {
+    const int64_t per_thread_min = 1 << 21;
+    if (threads > count / per_thread_min) threads = (int)(count / per_thread_min);
+    if (threads < 2) return decode_range_one(d, n, si, out, first, count);
+    std::vector<int> rc(threads, OASR_OK);
+    std::vector<std::string> msg(threads);     // the error text is per thread: carry it to the caller's
+    auto work = [&](int k) {
+        const int64_t lo = count * k / threads, hi = count * (k + 1) / threads;
+        Sink part = out;
+        if (part.o16) part.o16 += lo * si.channels;
+        if (part.o32) part.o32 += lo * si.channels;
+        rc[k] = decode_range_one(d, n, si, part, first + lo, hi - lo);
+        if (rc[k] != OASR_OK) msg[k] = oasr_last_error();
+    };
+    std::vector<std::thread> pool;
+    int started = 1;
+    try {
+        for (int k = 1; k < threads; ++k, ++started) pool.emplace_back(work, k);
+    } catch (...) {
+    }
+    work(0);
+    for (auto& t : pool) t.join();
+    for (int k = started; k < threads; ++k) work(k);     // parts whose thread could not be started
+    for (int k = 0; k < threads; ++k)
+        if (rc[k] != OASR_OK) {
+            set_error("%s", msg[k].c_str());
+            return rc[k];
+        }
+    return OASR_OK;
+}
+
 }  // namespace flac
 }  // namespace oasr
 
@@ -566,6 +670,35 @@ int oasr_flac_decode16(const uint8_t* data, int64_t size, int16_t* out, int64_t 
     sink.o16 = out;
     sink.shift = 16 - si.bits;
     return flac_decode_to(data, size, si, sink, capacity_per_channel, written_per_channel);
+}
+
+int oasr_flac_decode_range(const uint8_t* data, int64_t size, int64_t first, int64_t count, void* out, int32_t out_bits) {
+    OASR_REQUIRE(data && size > 0 && out, "flac_decode_range: null pointer");
+    OASR_REQUIRE(out_bits == 16 || out_bits == 32, "flac_decode_range: out_bits must be 16 or 32");
+    flac::StreamInfo si;
+    const int rc = flac::parse_header(data, (size_t)size, si);
+    if (rc != OASR_OK) return rc;
+    OASR_REQUIRE(si.total > 0, "flac_decode_range: the header states no sample count (decode the whole stream instead)");
+    OASR_REQUIRE(first >= 0 && count >= 0 && first + count <= si.total, "flac_decode_range: samples [%lld, %lld) lie outside the stream's %lld",
+                 (long long)first, (long long)(first + count), (long long)si.total);
+    OASR_REQUIRE(out_bits == 32 || si.bits <= 16, "flac_decode_range: the stream has %d bits per sample (at most 16 fit int16)", si.bits);
+    // a frame header of a fixed-block-size stream holds a frame number: its sample position is that number times
+    // the block size, which STREAMINFO must then state unambiguously (variable-block-size frames hold sample numbers)
+    const bool variable = (size_t)size > si.audio_start + 1 && (data[si.audio_start + 1] & 1);
+    OASR_REQUIRE(variable || (si.max_block > 0 && si.min_block == si.max_block),
+                 "flac_decode_range: STREAMINFO states block sizes %d..%d, so frame numbers do not give sample positions",
+                 si.min_block, si.max_block);
+    flac::Sink sink;
+    if (out_bits == 16) {
+        sink.o16 = static_cast<int16_t*>(out);
+        sink.shift = 16 - si.bits;
+    } else {
+        sink.o32 = static_cast<int32_t*>(out);
+    }
+    int threads = (int)std::thread::hardware_concurrency();
+    if (const char* env = getenv("OASR_FLAC_THREADS")) threads = atoi(env);
+    if (threads > 16) threads = 16;
+    return flac::decode_range((const uint8_t*)data, (size_t)size, si, sink, first, count, threads);
 }
 
 }  // extern "C"

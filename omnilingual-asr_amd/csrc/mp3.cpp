@@ -11,10 +11,11 @@
 // reference slices audio with (ref gemini_pipeline.py:273-285) — does.  Output: interleaved float32, nominally [-1, 1).
 // Free-format streams and Layers I / II are not decoded.
 //
-// Long files are decoded by several host threads, each on a range of frames: a thread starts 12 frames early and
-// discards what those produce, which is enough for every piece of state a frame inherits (bit reservoir <= 511 bytes,
-// one granule of overlap, 16 time slots of synthesis history) to equal that of an in-order decode, so the samples are
-// identical for any thread count.  OASR_MP3_THREADS in the environment overrides the count.
+// Long files are decoded by several host threads, each on a range of frames: a thread starts early enough (as many
+// frames as hold the largest bit reservoir, and two more: `warm_start`) and discards what those produce, so that
+// every piece of state a frame inherits (bit reservoir <= 511 bytes, one granule of overlap, 16 time slots of
+// synthesis history) equals that of an in-order decode and the samples are identical for any thread count.
+// OASR_MP3_THREADS in the environment overrides the count.
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -865,7 +866,28 @@ struct Decoder {
     }
 };
 
-static const int kWarmFrames = 12;
+// How far before frame `first` a decoder must start so that frame `first` comes out as in an in-order decode.
+// Frame `first` needs (a) the main data that main_data_begin can reach back to, (b) the overlap of the granule
+// before it and (c) 16 time slots of synthesis history - one granule, which in the second standard is a whole
+// frame whose own samples depend on the overlap of the frame before that.  So the two frames before `first`
+// must decode correctly, which takes the reservoir the earlier of them can point into: the walk goes back from
+// frame first - 3 until the main-data bytes gathered reach the largest main_data_begin (511 bytes; 255 in the
+// second standard).  At 128 kbit/s that is five frames in all; at 8 kbit/s and 22.05 kHz (13 bytes of main data
+// per frame) it is twenty-three - a fixed count of frames is wrong for one or wasteful for the other.
+static int64_t warm_start(const StreamPlan& sp, int64_t first) {
+    if (first <= 0) return 0;
+    const Header& h0 = sp.frames.front().h;
+    const int reach = h0.samples() == 576 ? 255 : 511;
+    int64_t f = first - 2 > 0 ? first - 2 : 0;
+    int gathered = 0;
+    for (int walked = 0; f > 0 && gathered < reach && walked < 512; ++walked) {
+        --f;
+        const Header& h = sp.frames[f].h;
+        const int md = h.frame_bytes - 4 - (h.crc ? 2 : 0) - h.side_bytes;
+        if (md > 0) gathered += md;
+    }
+    return f;
+}
 
 // Frames [first, last) of the plan; of what they produce, the output samples [lo, hi) of the stream go to
 // out[(s - lo) * channels ...].
@@ -876,7 +898,7 @@ static void decode_range(const uint8_t* d, const StreamPlan& sp, int64_t first, 
     const int nout = mono ? 1 : nch;
     const int spf = sp.frames.front().h.samples();
     std::vector<float> pcm((size_t)spf * 2);
-    const int64_t warm = first - kWarmFrames < 0 ? 0 : first - kWarmFrames;
+    const int64_t warm = warm_start(sp, first);
     for (int64_t f = warm; f < last; ++f) {
         Header h = sp.frames[f].h;
         if (h.channels != nch) {   // a channel-count change inside a stream: deliver silence of the stream's shape

@@ -104,6 +104,7 @@ _SIGNATURES = {
     "oasr_flac_info": (c_i32, [c_vp, c_i64, C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_i64), c_vp]),
     "oasr_flac_decode": (c_i32, [c_vp, c_i64, c_vp, c_i64, C.POINTER(c_i64)]),
     "oasr_flac_decode16": (c_i32, [c_vp, c_i64, c_vp, c_i64, C.POINTER(c_i64)]),
+    "oasr_flac_decode_range": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i32]),
     "oasr_adpcm_ima_decode": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, C.POINTER(c_i64)]),
     "oasr_mp3_info": (c_i32, [c_vp, c_i64, C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_i64)]),
     "oasr_mp3_decode": (c_i32, [c_vp, c_i64, c_vp, c_i64, C.POINTER(c_i64), c_vp]),

@@ -167,6 +167,25 @@ def map_wav_pcm(path):
     return np.frombuffer(mm, dtype=np.uint8, count=frames * block, offset=data_at), int(channels), int(rate), bits // 8, int(bits)
 
 
+def pcm_to_float(raw, sample_bytes: int, bits: int) -> np.ndarray:
+    """Integer samples as `map_wav_pcm` / `FlacStream.read_pcm` hand them over (any array over the sample bytes,
+    little-endian, 8-bit unsigned) -> flat float32, value = integer / 2^(bits - 1): the numbers `read_wav` and
+    `read_flac` deliver."""
+    raw = np.ascontiguousarray(raw).reshape(-1).view(np.uint8)
+    if sample_bytes == 1:
+        return (raw.astype(np.float32) - 128.0) / 128.0
+    if sample_bytes == 2:
+        return raw.view("<i2").astype(np.float32) / np.float32(1 << (bits - 1))
+    if sample_bytes == 3:
+        b = raw.reshape(-1, 3).astype(np.int32)
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        v = np.where(v & 0x800000, v - 0x1000000, v)
+        return v.astype(np.float32) / 8388608.0
+    if sample_bytes == 4:
+        return (raw.view("<i4").astype(np.float64) / float(1 << (bits - 1))).astype(np.float32)
+    raise UnsupportedAudioError(f"unsupported PCM width of {sample_bytes} bytes")
+
+
 def map_wav_pcm16(path):
     """(int16 [frames * channels] interleaved view of the memory-mapped file, channels, sample_rate) when `path`
     is a 16-bit PCM WAV (see `map_wav_pcm`), else None."""
@@ -446,6 +465,59 @@ def read_flac_pcm16(path):
         return None
     m = read_flac_pcm(path)
     return m[0], m[1], m[2]
+
+
+class FlacStream:
+    """A FLAC file decoded by sample ranges: `read_pcm(first, count)` returns the interleaved integer samples
+    [first, first + count) per channel exactly as `read_flac_pcm` delivers them, decoding only the frames that
+    cover the range.  The file is memory-mapped, so a reader that asks for one part of a long file touches only
+    that part's pages.  `sample_bytes` / `bits` say how a sample is stored (int16 scaled to 16 bits for streams
+    of at most 16 bits, else int32 at the stream's depth)."""
+
+    def __init__(self, path):
+        import ctypes as C
+
+        from . import _hip
+        self._lib = _hip.lib()
+        self._buf = np.memmap(path, dtype=np.uint8, mode="r")
+        rate, channels, bits, total = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+        try:
+            _hip.check(self._lib.oasr_flac_info(self._buf.ctypes.data, self._buf.size, C.byref(rate), C.byref(channels),
+                                                C.byref(bits), C.byref(total), None), "oasr_flac_info")
+        except _hip.OasrError as e:
+            raise UnsupportedAudioError(str(e)) from e
+        if total.value > self._buf.size * 8192:
+            raise UnsupportedAudioError("FLAC header declares %d samples, more than %d bytes can hold"
+                                        % (total.value, self._buf.size))
+        self.rate, self.channels, self.samples = int(rate.value), int(channels.value), int(total.value)
+        narrow = bits.value <= 16
+        self.sample_bytes, self.bits = (2, 16) if narrow else (4, int(bits.value))
+        # ranges can be located only when the frame headers give sample positions (a stated length, and a
+        # fixed block size or sample-numbered frames): one sample is asked for to find out
+        self.seekable = False
+        if self.samples > 0:
+            try:
+                self.read_pcm(0, 1)
+                self.seekable = True
+            except _hip.OasrError:
+                pass
+
+    def read_pcm(self, first: int, count: int) -> np.ndarray:
+        from . import _hip
+        out = np.empty((int(count) * self.channels,), dtype=np.int16 if self.sample_bytes == 2 else np.int32)
+        if count:
+            _hip.check(self._lib.oasr_flac_decode_range(self._buf.ctypes.data, self._buf.size, int(first), int(count),
+                                                        out.ctypes.data, 8 * self.sample_bytes), "oasr_flac_decode_range")
+        return out
+
+    def close(self) -> None:
+        self._buf = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 def _looks_like_mp3(head: bytes, path) -> bool:

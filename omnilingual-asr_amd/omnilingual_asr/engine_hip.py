@@ -50,6 +50,7 @@ class HipEngine:
         self._copy_stream = None
         self.use_graphs = use_graphs
         self._pcm_stage = None
+        self._pcm_stage_events = [None, None]
         self._copy_pool = None
         self.max_buffer_sets = 6        # distinct (batch, padded length) shapes kept resident
 
@@ -251,14 +252,19 @@ class HipEngine:
             dev = torch.empty((total,), dtype=torch.uint8, device=self.device)
             if self._pcm_stage is None:
                 self._pcm_stage = [torch.empty((block,), dtype=torch.uint8).pin_memory() for _ in range(2)]
-            events = [torch.cuda.Event(), torch.cuda.Event()]
+                self._pcm_stage_events = [None, None]
+            # A staging block may be overwritten only once the copy that last read it has finished - also a copy
+            # queued by an EARLIER call: with `on_device` this method returns without waiting for the device, so
+            # the events live on the engine, not in the call.
+            events = self._pcm_stage_events
             for i, off in enumerate(range(0, total, block)):
                 n = min(block, total - off)
                 stage = self._pcm_stage[i & 1]
-                if i >= 2:
+                if events[i & 1] is not None:
                     events[i & 1].synchronize()                          # the block's previous copy has left it
                 self._parallel_copy(stage.numpy(), raw, off, n)
                 dev[off: off + n].copy_(stage[:n], non_blocking=True)
+                events[i & 1] = torch.cuda.Event()
                 events[i & 1].record()
             mono = torch.empty((frames,), dtype=torch.float32, device=self.device)
             _hip.check(_hip.lib().oasr_pcm_to_mono_f32(dev.data_ptr(), frames, int(channels), int(sample_bytes), int(bits),

@@ -254,13 +254,94 @@ class ChunkRecord:
         return GeminiTranscriptionResult(summary=None, segments=[seg], detected_languages=None)
 
 
+class _Spans:
+    """A file read by sample ranges: `rate`, `samples` (per channel), `read(lo, hi)` -> the range in the file's own
+    form (runs on a helper thread), `to_16k(engine, payload)` -> that range as a mono 16 kHz signal, converted on the
+    device when the engine offers it (the signal then stays there) and by the host's converter otherwise."""
+    rate = 0
+    samples = 0
+
+    def close(self) -> None:
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class _Mp3Spans(_Spans):
+    def __init__(self, path):
+        self._stream = _audio.Mp3Stream(path)
+        self.rate, self.samples = self._stream.rate, self._stream.samples
+
+    def read(self, lo: int, hi: int):
+        return self._stream.read_mono(lo, hi - lo)                 # mono float32, the channel mean rounded once
+
+    def to_16k(self, engine, payload):
+        if hasattr(engine, "resample_16k"):
+            return engine.resample_16k(payload, self.rate)
+        return _audio.resample_poly(payload, self.rate, SAMPLE_RATE)
+
+    def close(self) -> None:
+        self._stream.close()
+
+
+class _PcmSpans(_Spans):
+    """Interleaved integer samples: a memory-mapped WAV's bytes (only the pages of a range are ever touched)."""
+
+    def __init__(self, raw, channels: int, rate: int, sample_bytes: int, bits: int):
+        self._raw = raw
+        self.channels, self.rate, self.sample_bytes, self.bits = channels, rate, sample_bytes, bits
+        self._frame = channels * sample_bytes
+        self.samples = int(raw.shape[0]) // self._frame if raw is not None else 0
+
+    def read(self, lo: int, hi: int):
+        return self._raw[lo * self._frame: hi * self._frame]
+
+    def to_16k(self, engine, payload):
+        if hasattr(engine, "pcm_to_16k"):
+            return engine.pcm_to_16k(payload, self.channels, self.rate, self.sample_bytes, self.bits,
+                                     on_device=hasattr(engine, "submit"))
+        x = _audio.pcm_to_float(payload, self.sample_bytes, self.bits).reshape(-1, self.channels)
+        mono = x.mean(axis=1, dtype=np.float64) if self.channels > 1 else x[:, 0]     # as `load_audio_16k` does
+        return _audio.resample_poly(mono, self.rate, SAMPLE_RATE)
+
+
+class _FlacSpans(_PcmSpans):
+    """A FLAC file: `read` decodes the frames that cover the range (`oasr_flac_decode_range`)."""
+
+    def __init__(self, path):
+        self._stream = _audio.FlacStream(path)
+        st = self._stream
+        super().__init__(None, st.channels, st.rate, st.sample_bytes, st.bits)
+        self.samples = st.samples
+        self.seekable = st.seekable
+
+    def read(self, lo: int, hi: int):
+        return self._stream.read_pcm(lo, hi - lo)
+
+    def close(self) -> None:
+        self._stream.close()
+
+
 def _is_deterministic(exc: BaseException) -> bool:
     """Errors that a second attempt or the next batch would meet again: a rejected kernel argument or an
-    unsupported shape (OasrError), a malformed batch (ValueError / TypeError), exhausted memory.  The
-    reference tolerates a failed chunk because its chunk is a network call (ref :635-641); none of
-    these is that kind of failure, so they are never swallowed."""
+    unsupported shape (OasrError), a malformed batch (ValueError / TypeError), exhausted host or device memory,
+    a device context that has faulted (torch reports both of the latter as RuntimeError subclasses or
+    RuntimeErrors whose text starts with the runtime's name).  The reference tolerates a failed chunk because
+    its chunk is a network call (ref :635-641); none of these is that kind of failure, so they are never
+    swallowed - a transcript with chunks silently missing would be the result."""
     from omnilingual_asr._hip import OasrError
-    return isinstance(exc, (OasrError, ValueError, TypeError, AssertionError, MemoryError))
+    if isinstance(exc, (OasrError, ValueError, TypeError, AssertionError, MemoryError)):
+        return True
+    if type(exc).__name__ in ("OutOfMemoryError", "AcceleratorError"):
+        return True
+    if isinstance(exc, RuntimeError):
+        text = str(exc).lstrip()
+        return text.startswith(("HIP error", "CUDA error", "HIP out of memory", "CUDA out of memory"))
+    return False
 
 
 class GeminiASRPipeline:
@@ -429,24 +510,55 @@ class GeminiASRPipeline:
             return records[0].to_result(word_timestamps=word_timestamps)
         return merge_results([self._transcribe_chunk(r, word_timestamps) for r in records])
 
-    def _encode_streamed(self, audio_path, word_timestamps: bool) -> Optional[GeminiTranscriptionResult]:
-        """A long MP3 in segments of two batches: host threads decode segment k + 1 while the device converts and
-        encodes segment k, instead of the whole file being decoded before the device starts.  Under a process
-        group a rank opens the stream and decodes only the samples of its own shard of chunks (the ordinary path
-        decodes the whole file on every rank); the records cross in the one all-gather.  Returns None when
-        the file or the engine is not of that kind (the ordinary path then runs).  The records equal the
-        ordinary path's bit for bit: every segment starts on a whole period of the rate converter and carries
-        enough input on both sides (a halo) for the converter's filter, so each 16 kHz sample is computed from
-        the same inputs by the same operations as in one pass over the file."""
+    def _open_span_source(self, audio_path):
+        """A reader that hands over any sample range of the file without the rest, or None: an MP3 (always), and -
+        under a process group, where a rank needs only its shard - an integer PCM WAV or a FLAC whose samples have
+        to be converted (a mono 16-bit WAV at 16 kHz is memory-mapped and sliced as it is)."""
+        eng = self.engine
+        if _audio.is_mp3(audio_path):
+            if self.process_group is None and not (hasattr(eng, "submit") and hasattr(eng, "resample_16k")):
+                return None                     # one process, host engine: nothing to overlap the decode with
+            return _Mp3Spans(audio_path)
+        if self.process_group is None:
+            return None
+        mapped = _audio.map_wav_pcm(audio_path)
+        if mapped is not None:
+            samples, channels, rate, sample_bytes, bits = mapped
+            if channels == 1 and rate == SAMPLE_RATE and sample_bytes == 2 and bits == 16:
+                return None
+            return _PcmSpans(samples, channels, rate, sample_bytes, bits)
+        with open(audio_path, "rb") as f:
+            head = f.read(4)
+        if head == b"fLaC":
+            try:
+                src = _FlacSpans(audio_path)
+            except Exception:
+                return None                     # the ordinary path reports what is wrong with the file
+            if src.samples > 0 and src.seekable:
+                return src
+            src.close()
+        return None
+
+    def _encode_streamed(self, audio_path, word_timestamps: bool, report=None) -> Optional[GeminiTranscriptionResult]:
+        """A long file in segments of two batches, each read, converted to 16 kHz and encoded on its own.  For an
+        MP3 on one GPU this overlaps the host decode of segment k + 1 with the device's work on segment k instead
+        of decoding the whole file first.  Under a process group it is what makes ingest sharded: a rank reads and
+        converts only the samples of its own contiguous shard of chunks (an MP3's frames, a FLAC's frames, the
+        bytes of a memory-mapped WAV; the ordinary path has every rank load the whole file), and the records cross
+        in the one all-gather.  Returns None when the file or the engine is not of that kind (the ordinary path
+        then runs).  The records equal the ordinary path's bit for bit: every segment starts on a whole period of
+        the rate converter and carries enough input on both sides (a halo) for the converter's filter, so each
+        16 kHz sample is computed from the same inputs by the same operations as in one pass over the file.
+        `report`: the progress callback's steps 1 and 2 are raised here, before the first segment is read and
+        before the records are exchanged and merged (ref :619, :644)."""
         from dataclasses import replace
         from fractions import Fraction
         eng = self.engine
-        if not (hasattr(eng, "submit") and hasattr(eng, "resample_16k")):
+        source = self._open_span_source(audio_path)
+        if source is None:
             return None
-        if not _audio.is_mp3(audio_path):
-            return None
-        with _audio.Mp3Stream(audio_path) as stream:
-            rate, total = stream.rate, stream.samples
+        with source:
+            rate, total = source.rate, source.samples
             fr = Fraction(SAMPLE_RATE, rate)
             up, down = fr.numerator, fr.denominator
             n16 = -(-total * up // down)
@@ -467,6 +579,7 @@ class GeminiASRPipeline:
                 return None                      # a segment would start inside a period of the converter
             halo = 0
             if rate != SAMPLE_RATE:
+                _audio.conversion_ratio(rate, SAMPLE_RATE)           # refuses rates no filter is designed for
                 half = _audio.polyphase_branches(rate, SAMPLE_RATE)[2]
                 halo = down * -(-(half // up + 2) // down)
 
@@ -478,6 +591,8 @@ class GeminiASRPipeline:
                 lo, hi = max(0, a_in - halo), min(total, b_in + halo)
                 return c1, a_out, b_out, a_in, lo, hi
 
+            if report:
+                report("transcribing", 1)
             from concurrent.futures import ThreadPoolExecutor
             records: List[ChunkRecord] = []
             decoded = [0]
@@ -485,15 +600,15 @@ class GeminiASRPipeline:
                 def fetch(c0):
                     _, _, _, _, lo, hi = span(c0)
                     decoded[0] += hi - lo
-                    return stream.read_mono(lo, hi - lo)
+                    return source.read(lo, hi)
                 pending = pool.submit(fetch, firsts[0]) if firsts else None
                 for i, c0 in enumerate(firsts):
-                    mono = pending.result()
+                    payload = pending.result()
                     if i + 1 < len(firsts):
                         pending = pool.submit(fetch, firsts[i + 1])
                     c1, a_out, b_out, a_in, lo, hi = span(c0)
                     with self._engine_lock:
-                        y = eng.resample_16k(mono, rate)
+                        y = source.to_16k(eng, payload)
                     drop = (a_in - lo) * up // down
                     signal = y[drop: drop + (b_out - a_out)]
                     if signal.shape[0] != b_out - a_out:
@@ -502,6 +617,8 @@ class GeminiASRPipeline:
                     for r in self._encode_chunks(signal, local, first_idx=c0):
                         records.append(replace(r, start_sample=r.start_sample + a_out, end_sample=r.end_sample + a_out))
             self._per_thread.decoded_source_samples = decoded[0]
+        if report:
+            report("processing", 2)
         if self.process_group is not None:
             records = _dist.exchange_records(records, bounds, self.process_group)
         if not records:
@@ -538,10 +655,9 @@ class GeminiASRPipeline:
                 progress_callback(step, idx)
 
         report("uploading", 0)
-        streamed = self._encode_streamed(audio_path, word_timestamps)   # long compressed file: decode and encode overlap
+        # a long compressed file (decode and encode overlap) or, under a process group, this rank's shard only
+        streamed = self._encode_streamed(audio_path, word_timestamps, report)
         if streamed is not None:
-            report("transcribing", 1)
-            report("processing", 2)
             report("done", 3)
             return streamed
         pcm = self._load_audio(audio_path)

@@ -320,7 +320,7 @@ def intensity_gains(pos, lsf, scale_sel=0):
 
 
 def encode(pcm, rate, *, seed=0, ms=False, crc=False, block_types=None, peak_is=1000, scalefactors=False,
-           reservoir=False, tables=None, all_big=False, mixed=False, intensity=None):
+           reservoir=False, tables=None, all_big=False, mixed=False, intensity=None, kbps=None):
     """pcm float64 [n, channels] -> (stream bytes, info).  `peak_is`: the largest quantised magnitude a granule aims
     for (int, or a list to draw from per granule).  info: 'snr_spectrum_db' (signal power over quantisation-error
     power of everything written), 'granules', 'frames', 'tables_used'."""
@@ -335,7 +335,10 @@ def encode(pcm, rate, *, seed=0, ms=False, crc=False, block_types=None, peak_is=
     g_total = frames * n_gr
     block_types = list(block_types) if block_types is not None else [0] * g_total
     block_types = (block_types * (g_total // len(block_types) + 1))[:g_total]
-    kbps = 160 if lsf else 320
+    rates_kbps = ([0, 8, 16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128, 144, 160] if lsf
+                  else [0, 32, 40, 48, 56, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320])
+    kbps = (160 if lsf else 320) if kbps is None else kbps
+    br_idx = rates_kbps.index(kbps)
     ver_bits = 3 if sr_idx < 3 else 2 if sr_idx < 6 else 0
     hdr = {"lsf": lsf, "sr_idx": sr_idx, "channels": ch,
            "side_bytes": (9 if ch == 1 else 17) if lsf else (17 if ch == 1 else 32)}
@@ -488,7 +491,7 @@ def encode(pcm, rate, *, seed=0, ms=False, crc=False, block_types=None, peak_is=
         joint = ms or intensity is not None
         mode = 3 if ch == 1 else (1 if joint else 0)
         h = bytes([0xFF, 0xE0 | (ver_bits << 3) | (1 << 1) | (0 if crc else 1),
-                   (14 << 4) | ((sr_idx % 3) << 2),
+                   (br_idx << 4) | ((sr_idx % 3) << 2),
                    (mode << 6) | (((2 if ms else 0) | (1 if intensity is not None else 0)) << 4)])
         out += h
         if crc:

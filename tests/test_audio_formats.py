@@ -274,3 +274,56 @@ def test_flac_pcm16_form_of_short_and_narrow_streams(tmp_path):
     data24, _ = _flac(1, 24, 48000, [[rng.integers(-(1 << 20), 1 << 20, 100).astype(np.int64)]], 0, [9], rice=14)
     p.write_bytes(data24)
     assert audio.read_flac_pcm16(p) is None
+
+
+def test_flac_sample_ranges_equal_the_whole_decode(golden_dir, tmp_path, monkeypatch):
+    """`FlacStream.read_pcm(first, count)` — only the frames that cover the range are decoded — against the
+    whole decode of the same long stream: ranges at the stream's start and end, inside one frame, across many
+    frames, empty; split over 1, 3 and 16 host threads; the 32-bit form of a 24-bit stereo stream; a range that
+    reaches past the end is refused; damage inside the range is reported, damage outside it is not seen."""
+    import flac_tools as ft
+
+    src = golden_dir / "reference_upload.flac"
+    x, rate = audio.read_flac(src)
+    ints = np.round(x * 32768.0).astype(np.int32)
+    stream, want = ft.repeat_stream(src.read_bytes(), 40, ints)
+    p = tmp_path / "long.flac"
+    p.write_bytes(stream)
+    total = want.shape[0]
+    rng = np.random.default_rng(11)
+    with audio.FlacStream(p) as fs:
+        assert (fs.rate, fs.channels, fs.samples, fs.sample_bytes, fs.bits) == (rate, 1, total, 2, 16)
+        ranges = [(0, 1), (0, 5000), (total - 1, 1), (total - 70000, 70000), (4096, 4096), (4095, 2), (1234567, 0),
+                  (0, total)]
+        ranges += [(int(a), int(rng.integers(1, min(total - a, 3_000_000) + 1))) for a in rng.integers(0, total - 1, 12)]
+        for threads in ("1", "3", "16"):
+            monkeypatch.setenv("OASR_FLAC_THREADS", threads)
+            for first, count in ranges:
+                got = fs.read_pcm(first, count)
+                assert got.dtype == np.int16 and np.array_equal(got.astype(np.int32), want[first: first + count, 0]), (threads, first, count)
+        with pytest.raises(Exception, match="outside the stream"):
+            fs.read_pcm(total - 10, 11)
+    # damage: one flipped bit at 3/4 of the file
+    bad = bytearray(stream)
+    at = len(bad) * 3 // 4
+    bad[at] ^= 0x10
+    p.write_bytes(bytes(bad))
+    monkeypatch.setenv("OASR_FLAC_THREADS", "1")
+    with audio.FlacStream(p) as fs:
+        head = fs.read_pcm(0, total // 2)
+        assert np.array_equal(head.astype(np.int32), want[: total // 2, 0])
+        with pytest.raises(Exception):
+            fs.read_pcm(total // 2, total - total // 2)
+    # 24-bit stereo: the int32 form
+    v = [rng.integers(-(1 << 20), 1 << 20, 4096).astype(np.int64) for _ in range(2 * 6)]
+    data24, want24 = _flac(2, 24, 48000, [[v[2 * i], v[2 * i + 1]] for i in range(6)], 0, [9, 9], rice=14)
+    p.write_bytes(data24)
+    with audio.FlacStream(p) as fs:        # the little writer states block sizes 16..65535: positions are unknown
+        with pytest.raises(Exception, match="frame numbers do not give sample positions"):
+            fs.read_pcm(0, 10)
+    p.write_bytes(data24[:8] + struct.pack(">HH", 4096, 4096) + data24[12:])
+    with audio.FlacStream(p) as fs:
+        assert (fs.channels, fs.sample_bytes, fs.bits, fs.samples) == (2, 4, 24, 6 * 4096)
+        for first, count in ((0, 6 * 4096), (4000, 200), (8192, 4096), (24575, 1)):
+            got = fs.read_pcm(first, count).reshape(-1, 2)
+            assert np.array_equal(got.astype(np.int64), want24[first: first + count])

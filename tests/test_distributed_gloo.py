@@ -154,3 +154,116 @@ def test_eight_ranks_shard_the_1140_chunk_plan_with_one_all_gather(tmp_path):
         assert o["ends"][-1] == 4000 * 1140 - 1500 and o["ends"][:-1] == [4000 * (i + 1) for i in range(1139)]
         assert o["frames"][0] == 11 and o["frames"][-1] == ((2500 - 400) // 160 + 1) // 2
         assert o["tok_frames"] == [[0, 1, 7]] * 3
+
+
+def _write_pcm_wav(path, seconds, rate, channels, width, seed=0):
+    """Integer PCM WAV of any width (1-4 bytes) by hand: the `wave` module is fine too, but this keeps 24 / 32 bits simple."""
+    import struct
+    rng = np.random.default_rng(seed)
+    n = int(seconds * rate)
+    t = np.arange(n) / rate
+    x = 0.2 * np.sin(2 * np.pi * 220.0 * t)[:, None] + 0.05 * rng.standard_normal((n, channels))
+    full = 1 << (8 * width - 1)
+    v = np.clip(np.round(x * (full - 1)), -full, full - 1).astype(np.int64)
+    if width == 1:
+        body = (v + 128).astype(np.uint8).tobytes()
+    else:
+        b = np.zeros((n, channels, width), dtype=np.uint8)
+        for k in range(width):
+            b[:, :, k] = (v >> (8 * k)) & 0xFF
+        body = b.tobytes()
+    fmt = struct.pack("<HHIIHH", 1, channels, rate, rate * channels * width, channels * width, 8 * width)
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(body)) + b"WAVE" + b"fmt " + struct.pack("<I", 16) + fmt
+                + b"data" + struct.pack("<I", len(body)) + body)
+
+
+def _worker_spans(rank, world, port, files, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pipe, eng = _make_pipeline(dist.group.WORLD)
+    out = {}
+    for f in files:
+        progress = []
+        segs = pipe.transcribe(f, progress_callback=lambda s, i: progress.append((s, i)))
+        out[f] = {"segs": [(s.start, s.end, s.speaker, s.text) for s in segs], "progress": progress,
+                  "read": pipe.gemini.decoded_source_samples}
+    torch.save(out, os.path.join(out_dir, f"spans{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_read_only_their_shards_of_wav_and_flac_files(tmp_path, golden_dir):
+    """Under a process group a rank reads and converts only the source samples of its own shard of chunks: a 48 kHz
+    stereo 16-bit WAV, a 44.1 kHz mono 24-bit WAV (ratio 160 / 441, so the converter's reach matters) and the
+    reference's FLAC upload (frames decoded by range).  Each rank touches about half of every file (its chunks plus
+    the converter's reach), and the merged result on both ranks equals the single-process result, which loads the
+    file whole."""
+    from omnilingual_asr import audio
+    files = [tmp_path / "stereo48.wav", tmp_path / "mono441.wav", golden_dir / "reference_upload.flac"]
+    _write_pcm_wav(files[0], 7.4, 48000, 2, 2, seed=1)
+    _write_pcm_wav(files[1], 6.3, 44100, 1, 3, seed=2)
+    totals = [int(7.4 * 48000), int(6.3 * 44100), 312060]
+    single, _ = _make_pipeline(None)
+    want = {str(f): [(s.start, s.end, s.speaker, s.text) for s in single.transcribe(str(f))] for f in files}
+    assert [len(want[str(f)]) for f in files] == [8, 7, 20]
+    port = _free_port()
+    mp.spawn(_worker_spans, args=(2, port, [str(f) for f in files], str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(tmp_path / f"spans{k}.pt") for k in range(2)]
+    for f, total in zip(files, totals):
+        a, b = r[0][str(f)], r[1][str(f)]
+        assert a["segs"] == want[str(f)] and b["segs"] == want[str(f)], f
+        assert a["progress"] == b["progress"] == [("uploading", 0), ("transcribing", 1), ("processing", 2), ("done", 3)]
+        # rank 0 holds the first ceil(n / 2) one-second chunks, rank 1 the rest (the last one short); each reads
+        # those source samples and the converter's reach (well under 1 000 samples a side), nothing more
+        n_chunks = len(want[str(f)])
+        rate = {0: 48000, 1: 44100, 2: 16000}[files.index(f)]
+        own0 = (n_chunks + 1) // 2 * rate
+        assert own0 <= a["read"] <= own0 + 1000, (f, a["read"], own0)
+        assert total - own0 <= b["read"] <= total - own0 + 1000, (f, b["read"], total - own0)
+
+
+def _worker8_wav(rank, world, port, wav, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    for p in (str(ROOT), str(ROOT / "omnilingual-asr_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from omnilingual_asr.models.inference.asr_pipeline import GeminiASRPipeline
+
+    calls = []
+    real = dist.all_gather
+    dist.all_gather = lambda *a, **k: (calls.append("all_gather"), real(*a, **k))[1]
+    eng = _PlanEngine()
+    pipe = GeminiASRPipeline(engine=eng, chunk_seconds=0.25, min_chunking_seconds=0.0, batch_size=32,
+                             process_group=dist.group.WORLD)
+    res = pipe.transcribe_chunked(wav)
+    dist.all_gather = real
+    torch.save({"calls": calls, "batches": eng.batches, "read": pipe.decoded_source_samples,
+                "starts": [s.start for s in res.segments], "ends": [s.end for s in res.segments]},
+               os.path.join(out_dir, f"w{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_each_read_an_eighth_of_a_48khz_stereo_wav(tmp_path):
+    """The 1 140-chunk plan (0.25 s chunks) on a 48 kHz stereo file of 285 s, world size 8: every rank reads its
+    143 or 142 chunks' worth of source samples plus the converter's reach per segment (3 segments of up to 64
+    chunks), nothing else; one all_gather; the merged plan is whole on every rank."""
+    wav = tmp_path / "long48.wav"
+    _write_pcm_wav(wav, 285.0 - 1500 / 16000.0, 48000, 2, 2, seed=4)
+    port = _free_port()
+    mp.spawn(_worker8_wav, args=(8, port, str(wav), str(tmp_path)), nprocs=8, join=True)
+    outs = [torch.load(tmp_path / f"w{r}.pt") for r in range(8)]
+    per_chunk = 12000                                   # source samples per channel in 0.25 s
+    for r, o in enumerate(outs):
+        n_chunks = 143 if r < 4 else 142
+        assert o["calls"] == ["all_gather"]
+        assert o["batches"] == [32, 32, 32, 32, 15 if r < 4 else 14]
+        assert len(o["starts"]) == 1140 and o["starts"] == [0.25 * i for i in range(1140)]
+        assert abs(o["ends"][-1] - (285.0 - 1500 / 16000.0)) < 1e-3
+        own = n_chunks * per_chunk - (4500 if r == 7 else 0)
+        assert own <= o["read"] <= own + 3 * 2 * 200, (r, o["read"], own)     # + the reach (<= 200 samples a side)
+    assert sum(o["read"] for o in outs) < 1.01 * 48000 * 285

@@ -244,3 +244,55 @@ def test_batches_gathered_on_the_device_equal_batches_assembled_on_the_host(tmp_
     with pytest.raises(ValueError):
         t, _ = pipe.engine.host_batch_slot(1, 480000, 0)
         pipe.engine.submit(t, [480000], source=(dev, [total - 10]))     # runs past the end of the signal
+
+
+def test_back_to_back_device_decodes_do_not_share_staging_memory_too_early():
+    """`pcm_to_16k(on_device=True)` returns while its last uploads may still be reading the two page-locked
+    staging blocks; the next call (another thread's file in the server) must wait for them before it refills the
+    blocks.  Two multi-block inputs (three and two blocks of 48 MiB) back to back, no synchronisation between the
+    calls: each result must be the host decode of its own input (16 kHz mono 16-bit, so the device result is
+    exactly sample / 32768)."""
+    from omnilingual_asr.engine_hip import HipEngine
+    eng = HipEngine("GTINY", seed=0)
+    rng = np.random.default_rng(5)
+    block = 12 << 22
+    a = rng.integers(-32768, 32768, (2 * block + 1000) // 2, dtype=np.int16)          # 2 blocks and a bit
+    b = (rng.integers(-32768, 32768, (block + 4096) // 2, dtype=np.int16) | 1)       # 1 block and a bit, all odd
+    ya = eng.pcm_to_16k(a, 1, 16000, 2, 16, on_device=True)
+    yb = eng.pcm_to_16k(b, 1, 16000, 2, 16, on_device=True)
+    yc = eng.pcm_to_16k(a[: block // 2 + 7], 1, 16000, 2, 16, on_device=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(ya.cpu().numpy(), a.astype(np.float32) / 32768.0)
+    assert np.array_equal(yb.cpu().numpy(), b.astype(np.float32) / 32768.0)
+    assert np.array_equal(yc.cpu().numpy(), a[: block // 2 + 7].astype(np.float32) / 32768.0)
+
+
+def test_progress_steps_of_the_segmented_path_arrive_around_the_work(golden_dir):
+    """The reference reports "transcribing" before it fans its chunks out and "processing" before it merges
+    (ref gemini_pipeline.py:619, :644).  On the segmented path (a long MP3) step 1 must arrive before the first
+    batch is submitted to the engine and step 2 after the last batch was collected, not all at the end."""
+    import time
+    from omnilingual_asr import Pipeline
+
+    pipe = Pipeline(model="GTINY", seed=4, batch_size=2, chunk_seconds=2.5, min_chunking_seconds=2.5).gemini
+    eng = pipe.engine
+    stamps = {"submit": [], "collect": []}
+    real_submit, real_collect = eng.submit, eng.collect
+
+    def submit(*a, **k):
+        stamps["submit"].append(time.perf_counter())
+        return real_submit(*a, **k)
+
+    def collect(*a, **k):
+        out = real_collect(*a, **k)
+        stamps["collect"].append(time.perf_counter())
+        return out
+    eng.submit, eng.collect = submit, collect
+    steps = []
+    res = pipe.transcribe_chunked(golden_dir / "reference_demo_40s.mp3",
+                                  progress_callback=lambda s, i: steps.append((s, i, time.perf_counter())))
+    assert [(s, i) for s, i, _ in steps] == [("uploading", 0), ("transcribing", 1), ("processing", 2), ("done", 3)]
+    assert len(res.segments) == 16 and len(stamps["submit"]) == 8 == len(stamps["collect"])
+    t = {s: at for s, _, at in steps}
+    assert t["uploading"] < t["transcribing"] < min(stamps["submit"])
+    assert max(stamps["collect"]) < t["processing"] < t["done"]

@@ -282,6 +282,31 @@ def test_two_ranks_decode_only_their_shards_of_an_mp3():
     assert len(lines) == 2 and all("equal to the unsharded result: True" in l for l in lines), lines
 
 
+def test_two_ranks_read_only_their_shards_of_a_stereo_wav_and_a_flac():
+    """The same for uncompressed and lossless input: a 48 kHz 16-bit stereo WAV (memory-mapped; a rank uploads and
+    converts only the bytes of its shard, on the device) and the reference's FLAC upload (a rank decodes only the
+    frames that cover its shard).  Each of the two ranks reads about half of the source samples and the merged
+    result equals the unsharded one, which loads the file whole (tools/sharded_mp3.py wav flac)."""
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(root / "tools" / "sharded_mp3.py"), "wav", "flac"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=str(root))
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("rank ")]
+    assert len(lines) == 4 and all("equal to the unsharded result: True" in l for l in lines), lines
+    for l in lines:
+        pct = int(l.rsplit("(", 1)[1].split()[0])
+        assert 40 <= pct <= 60, l
+
+
 def test_four_threads_share_one_pipeline(tmp_path):
     """The reference's server runs up to four `transcribe()` calls at once on one shared instance
     (ref:workflows/wav2elan_web/app.py:383-399): results must equal the one-at-a-time results."""

@@ -327,3 +327,32 @@ def test_mp3_through_transcribe(golden_dir, tiny_engine):
     n16 = -(-(1531 * 1152 - 576 - 1190) * 160 // 441)
     assert len(segs) == 2 and segs[0].start == 0.0 and segs[0].end == 30.0 and segs[1].start == 30.0
     assert segs[1].end == pytest.approx(n16 / 16000.0, abs=1e-6) and all(s.text for s in segs)
+
+
+def test_low_bitrate_stream_with_a_deep_reservoir_decodes_the_same_from_any_start(tmp_path, monkeypatch):
+    """8 kbit/s at 22.05 kHz (second standard, mono): a frame is 26 bytes of which 13 are main data, and
+    main_data_begin reaches its maximum of 255 bytes, so a frame's data begins about twenty frames before it.  A
+    worker thread or a sample range that starts inside the stream has to gather that much main data (and decode the
+    two frames before its first one for the overlap and the synthesis history) before its first frame is right: the
+    samples must not depend on the thread count or on where a range starts."""
+    rng = np.random.default_rng(8)
+    n = 576 * 400
+    t = np.arange(n) / 22050.0
+    pcm = (0.02 * np.sin(2 * np.pi * 300.0 * t) * (1.5 + np.sin(2 * np.pi * 1.3 * t)) + 0.0002 * rng.standard_normal(n))[:, None]
+    data, info = mt.encode(pcm, 22050, kbps=8, reservoir=True, peak_is=[1, 1, 2], seed=3)
+    assert info["frame_bytes"] == 26
+    begins = [((data[26 * f + 4] << 8 | data[26 * f + 5]) >> 8) & 0xFF for f in range(info["frames"])]   # 8 bits in the LSF side info
+    assert max(begins) == 255 and np.mean(np.array(begins[40:]) > 200) > 0.5                      # the reservoir is deep
+    p = tmp_path / "low.mp3"
+    p.write_bytes(data)
+    monkeypatch.setenv("OASR_MP3_THREADS", "1")
+    whole, rate = audio.read_mp3_mono(p)
+    assert rate == 22050 and float(np.abs(whole).max()) > 0.005
+    for th in ("2", "5", "9"):
+        monkeypatch.setenv("OASR_MP3_THREADS", th)
+        got, _ = audio.read_mp3_mono(p)
+        assert np.array_equal(got, whole), th
+    monkeypatch.setenv("OASR_MP3_THREADS", "1")
+    with audio.Mp3Stream(p) as st:
+        for first, count in ((576 * 100 + 7, 5000), (576 * 37, 576), (576 * 250 - 1, 20000), (0, 3000)):
+            assert np.array_equal(st.read_mono(first, count), whole[first: first + count]), (first, count)

@@ -57,12 +57,13 @@ def test_static_entry_point_equals_workspace_entry_point_twice():
             np.testing.assert_array_equal(got[1][b, :n], ref[b][1])
     # a further call with every buffer already in place leaves the device's free memory as it was
     tok = torch.zeros((batch, t_pad), dtype=torch.int32, device="cuda")
+    frm = torch.zeros((batch, t_pad), dtype=torch.int32, device="cuda")
     cnt = torch.zeros((batch,), dtype=torch.int32, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
     torch.cuda.synchronize()
     free_before = torch.cuda.mem_get_info()[0]
     H.check(H.lib().oasr_ctc_greedy_static(lg_d.data_ptr(), ld, vocab, len_d.data_ptr(), batch, t_pad, 0,
-                                           tok.data_ptr(), tok.data_ptr(), cnt.data_ptr(), st))
+                                           tok.data_ptr(), frm.data_ptr(), cnt.data_ptr(), st))
     torch.cuda.synchronize()
     assert torch.cuda.mem_get_info()[0] == free_before
 

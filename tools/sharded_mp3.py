@@ -1,32 +1,67 @@
 #!/usr/bin/env python3
-"""Rehearsal of the sharded path on a compressed file: run under torch.distributed.run with N ranks (gloo; the ranks
-may share GPU 0).  Every rank calls the public long-audio entry on the same MP3; each decodes only the samples of its
-own shard of chunks, the records cross in the one all-gather, and every rank checks the merged result against a
-pipeline without a process group.  Usage: python -m torch.distributed.run --nproc-per-node 2 tools/sharded_mp3.py"""
-import os, sys
+"""Rehearsal of sharded ingest: run under torch.distributed.run with N ranks (gloo; the ranks may share GPU 0).
+Every rank calls the public long-audio entry on the same file; each reads and converts only the samples of its own
+shard of chunks (MP3 frames, FLAC frames, the bytes of a memory-mapped WAV), the records cross in the one all-gather,
+and every rank checks the merged result against a pipeline without a process group, which loads the file whole.
+Usage: python -m torch.distributed.run --nproc-per-node 2 tools/sharded_mp3.py [mp3|wav|flac ...]   (default: mp3)"""
+import os, struct, sys, tempfile
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "omnilingual-asr_amd"))
+import numpy as np
 import torch
 import torch.distributed as dist
 from omnilingual_asr.models.inference.asr_pipeline import GeminiASRPipeline
 
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-path = ROOT / "tests" / "golden" / "reference_demo_40s.mp3"
-kw = dict(model="GTINY", seed=4, batch_size=2, chunk_seconds=2.5, min_chunking_seconds=2.5)
-sharded = GeminiASRPipeline(process_group=dist.group.WORLD, **kw)
-got = sharded.transcribe_chunked(path, word_timestamps=True)
-share = sharded.decoded_source_samples
-alone = GeminiASRPipeline(**kw)
-want = alone._encode_file(alone._load_audio(path), True)
-same = len(got.segments) == len(want.segments) and all(
-    (a.start, a.end, a.text, a.words) == (b.start, b.end, b.text, b.words) for a, b in zip(got.segments, want.segments))
-total = 1531 * 1152 - 576 - 1190
-ok = same and share < total * (1.0 / world + 0.05) and any(s.text for s in got.segments)
-print("rank %d of %d: %d segments, equal to the unsharded result: %s, decoded %d of %d source samples (%.0f %%)"
-      % (rank, world, len(got.segments), same, share, total, 100.0 * share / total), flush=True)
-flag = torch.tensor([1 if ok else 0])
+golden = ROOT / "tests" / "golden"
+
+
+def stereo_wav_48k(path, seconds=40.0):
+    """48 kHz 16-bit stereo: speech-band noise bursts, different in the two channels."""
+    rng = np.random.default_rng(7)
+    n = int(seconds * 48000)
+    t = np.arange(n) / 48000.0
+    x = (0.2 * np.sin(2 * np.pi * 180.0 * t) * (np.sin(2 * np.pi * 0.7 * t) > 0))[:, None] + 0.05 * rng.standard_normal((n, 2))
+    body = np.clip(np.round(x * 32767), -32768, 32767).astype("<i2").tobytes()
+    fmt = struct.pack("<HHIIHH", 1, 2, 48000, 48000 * 4, 4, 16)
+    path.write_bytes(b"RIFF" + struct.pack("<I", 36 + len(body)) + b"WAVE" + b"fmt " + struct.pack("<I", 16) + fmt
+                     + b"data" + struct.pack("<I", len(body)) + body)
+    return n
+
+
+kinds = sys.argv[1:] or ["mp3"]
+ok_all = True
+for kind in kinds:
+    if kind == "mp3":
+        path, total = golden / "reference_demo_40s.mp3", 1531 * 1152 - 576 - 1190
+    elif kind == "flac":
+        path, total = golden / "reference_upload.flac", 312060
+    else:
+        path = Path(tempfile.gettempdir()) / ("oasr_sharded_%d.wav" % os.getppid())
+        total = int(40.0 * 48000)
+        if rank == 0:
+            stereo_wav_48k(path)
+        dist.barrier()
+    kw = dict(model="GTINY", seed=4, batch_size=2, chunk_seconds=2.5, min_chunking_seconds=2.5)
+    sharded = GeminiASRPipeline(process_group=dist.group.WORLD, **kw)
+    got = sharded.transcribe_chunked(path, word_timestamps=True)
+    share = sharded.decoded_source_samples
+    alone = GeminiASRPipeline(**kw)
+    want = alone._encode_file(alone._load_audio(path), True)
+    same = len(got.segments) == len(want.segments) and all(
+        (a.start, a.end, a.text, a.words) == (b.start, b.end, b.text, b.words) for a, b in zip(got.segments, want.segments))
+    # a shard is a whole number of chunks: at most one chunk more than an even split, plus the converter's reach
+    limit = total * (1.0 / world) + (total / max(len(want.segments), 1)) + 2000
+    ok = same and 0 < share <= limit and any(s.text for s in got.segments)
+    ok_all = ok_all and ok
+    print("rank %d of %d, %s: %d segments, equal to the unsharded result: %s, read %d of %d source samples (%.0f %%)"
+          % (rank, world, kind, len(got.segments), same, share, total, 100.0 * share / total), flush=True)
+    dist.barrier()
+    if kind == "wav" and rank == 0:
+        path.unlink()
+flag = torch.tensor([1 if ok_all else 0])
 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
 dist.destroy_process_group()
 sys.exit(0 if int(flag) == 1 else 1)
