@@ -437,8 +437,11 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": "fp8 (e4m3) projections, bf16 elsewhere" if args.fp8 else "bf16",
             "data": "synthetic (seeded noise + 440 Hz tone), random-init weights seed 0",
-            "config": {"workload": ("BASELINE configs[2]" if g.name == "G300" else "BASELINE configs[4]" if args.fp8 else
-                                    "geometry of BASELINE configs[4] in bf16") + (" fp8" if args.fp8 and g.name == "G300" else "") +
+            "config": {"workload": (("BASELINE configs[1]" if args.batch == 1 else "BASELINE configs[2]" if args.batch == 32
+                                     else "geometry of BASELINE configs[2] at another batch size") if g.name == "G300"
+                                    else "BASELINE configs[4]" if args.fp8 and args.batch == 8 else
+                                    "geometry of BASELINE configs[4]" + ("" if args.fp8 else " in bf16")) +
+                                   (" fp8" if args.fp8 and g.name == "G300" else "") +
                                    ": batch=%d x %.0f s chunks @16 kHz, log-mel + %s encoder "
                                    "(%d blocks, d=%d, %.0fM params), %s" %
                                    (args.batch, args.seconds, g.name, g.n_layers, g.d_model, g.n_params() / 1e6,

@@ -512,6 +512,164 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_small_kernel(const uint16_t*
                           smem + 2 * kRing * kSmallSlice + wave * kEpiSlab, c_packed);
 }
 
+// Stream variant for small problems (a single utterance: 12 row tiles).  At that size a work-group
+// has a CU to itself or shares it with one other, and the kernel above - every wave copying its share of
+// slice p + 2 between its fragment reads and its MFMAs - runs at the latency of a global -> LDS copy per
+// two slices (0.45 us per slice measured on 1536 x 1024 x 4096: 57 us, 0.09 of the MFMA peak).  Here the
+// copying and the arithmetic belong to different waves: waves 4-7 (producers) do nothing but keep a ring
+// of eight slices filled, up to five slices ahead of the arithmetic; waves 0-3 (consumers) read the
+// fragments of slice p + 1 from LDS while their MFMAs run on slice p.  One s_barrier per slice:
+//   barrier_p is passed once every producer has seen its pieces of slices <= p + 1 land;
+//   after it the consumers read slice p + 1 and multiply slice p (whose fragments they hold), and the
+//   producers refill the ring slot of slice p - 1 (its fragments were in registers before the consumers
+//   arrived at barrier_p) with slice p + 7.
+// Tile 128 x TN with TN = 128 (consumers 2 x 2, a wave owns 64 x 64) or TN = 64 (consumers 4 x 1, a wave
+// owns 32 x 64: twice the work-groups when 128 x 128 tiles would leave most CUs idle).  Same K slices,
+// swizzle, MFMA, accumulation order (from the bias, slice by slice) and epilogues as the other kernels:
+// every output element is computed by the same sequence of operations, so results stay bit-identical to
+// them - which is why K is not split over work-groups here: a split sum is another sum, and an
+// utterance's states would depend on the batch it was in.
+constexpr int kStreamRing = 8;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_slices(int slices) {   // s_waitcnt vmcnt(N * slices), slices in 0 .. 6
+    switch (slices) {
+        case 0: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(0) : "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * N) : "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * N) : "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * N) : "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * N) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * N) : "memory"); break;
+    }
+}
+
+template <int EPI, int TN>
+__global__ __launch_bounds__(512) void gemm_bf16_stream_kernel(const uint16_t* __restrict__ A,
+                                                               const uint16_t* __restrict__ W,
+                                                               const float* __restrict__ bias, const float* resid,
+                                                               void* C, int64_t N, int64_t K, float alpha,
+                                                               int tiles_m, int n_tiles, int flags) {
+    // consumer waves: CWM x CWN, a wave owns (16 MI) x 64 of the tile
+    constexpr int TM = 128, CWN = TN / 64, CWM = 4 / CWN, kConsumers = 4;
+    constexpr int MI = TM / (16 * CWM);
+    constexpr int kRingSlots = kStreamRing;                            // 8 x 16 or 12 KiB
+    constexpr int kSlotA = TM * BK * 2, kSlot = (TM + TN) * BK * 2;
+    constexpr int kAPieces = TM / 64, kWPieces = TN / 64;              // pieces (16 rows) per producer wave and slice
+    constexpr int kCopies = kAPieces + kWPieces;                       // copies per producer wave and slice
+    const bool w_packed = flags & OASR_GEMM_W_PACKED, a_packed = flags & OASR_GEMM_A_PACKED, c_packed = flags & OASR_GEMM_C_PACKED;
+    __shared__ __attribute__((aligned(1024))) char smem[kRingSlots * kSlot + kConsumers * kEpiSlab];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile;
+    {   // contiguous run of tiles per XCD (work-groups with equal blockIdx % 8 share one), m fastest; cutting the
+        // tile grid into one compact block per XCD instead changed no shape's time
+        const int q8 = n_tiles / 8, r8 = n_tiles % 8, xcd = blockIdx.x % 8;
+        tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + blockIdx.x / 8;
+    }
+    const int tile_m = tile % tiles_m, tile_n = tile / tiles_m;
+    const int64_t m0 = (int64_t)tile_m * TM, n0 = (int64_t)tile_n * TN;
+    const int nph = (int)(K / BK);
+
+    if (wave >= kConsumers) {
+        // ---- producers: wave pw copies A pieces kAPieces pw .. and W pieces kWPieces pw .. of every slice
+        const int pw = wave - kConsumers;
+        const uint32_t lane_off =
+            (uint32_t)(((lane >> 2) * K + (((lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3)) << 3)) * 2);
+        const int64_t piece_stride = 16 * K * 2;
+        const uint32_t lane_off_w = w_packed ? (uint32_t)lane * 16 : lane_off;
+        const int64_t piece_stride_w = w_packed ? (int64_t)nph * 1024 : piece_stride;
+        const int w_step = w_packed ? 1024 : BK * 2;
+        const uint32_t lane_off_a = a_packed ? (uint32_t)lane * 16 : lane_off;
+        const int64_t piece_stride_a = a_packed ? (int64_t)nph * 1024 : piece_stride;
+        const int a_step = a_packed ? 1024 : BK * 2;
+        const int64_t a_row = m0 + pw * (16 * kAPieces), w_row = n0 + pw * (16 * kWPieces);
+        const char* st_a = reinterpret_cast<const char*>(A) + (a_packed ? (a_row >> 4) * (int64_t)nph * 1024 : a_row * K * 2);
+        const char* st_w = reinterpret_cast<const char*>(W) + (w_packed ? (w_row >> 4) * (int64_t)nph * 1024 : w_row * K * 2);
+        auto issue = [&](int p) {
+            char* slot = smem + (p % kRingSlots) * kSlot;
+#pragma unroll
+            for (int i = 0; i < kAPieces; ++i)
+                __builtin_amdgcn_global_load_lds((gbl_void*)(st_a + i * piece_stride_a + lane_off_a),
+                                                 (lds_void*)(slot + (pw * kAPieces + i) * 1024), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < kWPieces; ++i)
+                __builtin_amdgcn_global_load_lds((gbl_void*)(st_w + i * piece_stride_w + lane_off_w),
+                                                 (lds_void*)(slot + kSlotA + (pw * kWPieces + i) * 1024), 16, 0, 0);
+            st_a += a_step;
+            st_w += w_step;
+        };
+        int issued = 0;
+        for (; issued < kRingSlots - 1 && issued < nph; ++issued) issue(issued);
+        for (int it = 0; it < nph; ++it) {
+            // slices <= it + 1 must have landed: everything issued but the newest (issued - it - 2) slices
+            const int ahead = issued - it - 2;
+            wait_vmcnt_slices<kCopies>(ahead < 0 ? 0 : ahead);
+            OASR_RAW_BARRIER();
+            // slice it + kRingSlots - 1 goes into the slot of slice it - 1, whose fragments the consumers had in
+            // registers before they arrived at barrier_it (the slot of slice `it` itself may still be being read:
+            // slice 0 is read after barrier_0)
+            if (issued < nph) issue(issued++);
+        }
+        return;
+    }
+
+    // ---- consumers
+    const int wm = wave / CWN, wn = wave % CWN;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int off = fr * 64 + ((fq ^ ((4 - (fr >> 2)) & 3)) << 4);
+    f32x4 acc[MI][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (EPI != OASR_EPI_GLU_BF16 && bias) {
+            const float4 t = *reinterpret_cast<const float4*>(bias + n0 + wn * 64 + j * 16 + fq * 4);
+            b = (f32x4){t.x, t.y, t.z, t.w};
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[i][j] = b;   // the accumulators start from the bias
+    }
+    bf16x8 xf[2][MI], wf[2][4];
+    auto read_frags = [&](int p, bf16x8 (&x)[MI], bf16x8 (&w)[4]) {
+        const char* slot = smem + (p % kRingSlots) * kSlot;
+        const char* sa = slot + (wm * 16 * MI) * 64 + off;
+        const char* sb = slot + kSlotA + (wn * 64) * 64 + off;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 64);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) x[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 64);
+    };
+    auto multiply = [&](const bf16x8 (&x)[MI], const bf16x8 (&w)[4]) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j], x[i], acc[i][j], 0, 0, 0);
+    };
+    // A consumer passes barrier_p only with the fragments of slice p in its registers (the producers overwrite
+    // that slot next): the LDS counter is drained in front of every barrier (the reads were issued a whole
+    // MFMA batch earlier, so this does not wait in practice).
+#define OASR_CONSUMER_BARRIER()                                \
+    do {                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+        OASR_RAW_BARRIER();                                    \
+    } while (0)
+    OASR_RAW_BARRIER();                              // barrier_0: slices 0 and 1 are in LDS
+    read_frags(0, xf[0], wf[0]);
+    for (int it = 0; it < nph; it += 2) {
+        if (it + 1 < nph) read_frags(it + 1, xf[1], wf[1]);
+        multiply(xf[0], wf[0]);
+        if (it + 1 >= nph) break;
+        OASR_CONSUMER_BARRIER();                     // barrier_(it + 1)
+        if (it + 2 < nph) read_frags(it + 2, xf[0], wf[0]);
+        multiply(xf[1], wf[1]);
+        if (it + 2 < nph) OASR_CONSUMER_BARRIER();   // barrier_(it + 2)
+    }
+#undef OASR_CONSUMER_BARRIER
+    gemm_epilogue<EPI, MI>(acc, resid, C, N, alpha, m0 + wm * 16 * MI, n0 + wn * 64, lane,
+                           smem + kRingSlots * kSlot + wave * kEpiSlab, c_packed);
+}
+
 // Row-major bf16 weights [n][k] -> the packed form read by the kernels above: one thread per 16-byte chunk;
 // chunk `lane` of piece (row group g, K slice t) is row 16 g + (lane >> 2), source chunk
 // (lane & 3) ^ (-(row >> 2) & 3) of the slice, as lane_off places it.
@@ -547,6 +705,48 @@ static int gemm_bf16_launch(const uint16_t* a, const uint16_t* w, const float* b
     OASR_REQUIRE(!(flags & OASR_GEMM_C_PACKED) || epilogue == OASR_EPI_BIAS_BF16 || epilogue == OASR_EPI_BIAS_SWISH_BF16,
                  "gemm: packed output exists for the two bf16 bias epilogues only");
     const int tiles = (int)((m / BM) * (n / BN));
+#ifndef OASR_SMALL_STREAM
+#define OASR_SMALL_STREAM 1
+#endif
+#ifndef OASR_STREAM_TN_CUT
+#define OASR_STREAM_TN_CUT 128
+#endif
+    if (OASR_SMALL_STREAM && tiles < kMaxCUs / 2 && (m / 128) * (n / 128) <= kMaxCUs) {
+        // Small problems (a single utterance) whose 128 x 128 tiles number at most one per CU: producer /
+        // consumer waves on 128 x 128 tiles, or on 128 x 64 tiles when the former would occupy at most half of
+        // the CUs; same arithmetic per output element as every other path.  Measured for one 30 s utterance
+        // (1536 rows) inside the step, against the kernel below: FFN down-projection and d x d projections
+        // 36.2 -> 21.1 us on average, GLU 15.7 -> 13.3.  A work-group takes in 50-60 GB/s whatever its shape -
+        // what a CU's global -> LDS path delivered in every variant tried (four or eight producer waves, 128 x 64
+        // to 256 x 128 tiles, tiles grouped per XCD or not) - so the time is the bytes of the busiest CU.  With
+        // more tiles than CUs the kernel below, two work-groups to a CU, is as fast (FFN up-projection, 384
+        // tiles: 21.5 us against 26.8 on 128 x 128 and 20.0 on 256 x 128 tiles here; QKV 16.8 against 23.0 and
+        // 18.9) and stays in charge.
+        const int64_t t128 = (m / 128) * (n / 128);
+        const int tile_m = 128, tile_n = t128 <= OASR_STREAM_TN_CUT ? 64 : 128;
+        const int tm = (int)(m / tile_m), tn = (int)(n / tile_n), nt = tm * tn;
+        hipStream_t st = (hipStream_t)stream;
+#define OASR_LAUNCH_STREAM(E)                                                                                              \
+    do {                                                                                                                   \
+        if (tile_n == 64)                                                                                                  \
+            hipLaunchKernelGGL((gemm_bf16_stream_kernel<E, 64>), dim3((unsigned)nt), dim3(512), 0, st, a, w, bias, resid, c, n, k, alpha, tm, nt, flags);  \
+        else                                                                                                               \
+            hipLaunchKernelGGL((gemm_bf16_stream_kernel<E, 128>), dim3((unsigned)nt), dim3(512), 0, st, a, w, bias, resid, c, n, k, alpha, tm, nt, flags); \
+    } while (0)
+        switch (epilogue) {
+            case OASR_EPI_BIAS_BF16: OASR_LAUNCH_STREAM(OASR_EPI_BIAS_BF16); break;
+            case OASR_EPI_BIAS_SWISH_BF16: OASR_LAUNCH_STREAM(OASR_EPI_BIAS_SWISH_BF16); break;
+            case OASR_EPI_GLU_BF16: OASR_LAUNCH_STREAM(OASR_EPI_GLU_BF16); break;
+            case OASR_EPI_RESIDUAL_F32: OASR_LAUNCH_STREAM(OASR_EPI_RESIDUAL_F32); break;
+            case OASR_EPI_BIAS_F32: OASR_LAUNCH_STREAM(OASR_EPI_BIAS_F32); break;
+            default:
+                set_error("gemm: unknown epilogue %d", epilogue);
+                return OASR_EINVAL;
+        }
+#undef OASR_LAUNCH_STREAM
+        OASR_CHECK_LAUNCH("gemm (stream)");
+        return OASR_OK;
+    }
     if (tiles < kMaxCUs / 2) {   // 256 x 256 tiles for fewer than half of the CUs: 128 x 128 tiles, same arithmetic
         // (measured: faster below ~128 large tiles, slower at 192)
         const int tm = (int)(m / kSmallTile), nt = tm * (int)(n / kSmallTile);

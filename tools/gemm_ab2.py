@@ -2,7 +2,7 @@
 """In-process A/B timing of GEMM kernel variants (libraries built by tools/build_gemm_variants.sh):
 rounds interleave the variants on the same operands; median and minimum per variant and shape, and a
 check that every variant's output equals the first one's bit for bit.
-Usage: gemm_ab2.py lib1.so lib2.so ..."""
+Usage: gemm_ab2.py [--rows M] lib1.so lib2.so ...   (--rows 1536: the shapes of a single 30 s utterance)"""
 import ctypes as C
 import sys
 from pathlib import Path
@@ -11,15 +11,26 @@ import torch
 
 libs = []
 vp = C.c_void_p
-for path in sys.argv[1:]:
+argv = sys.argv[1:]
+M = 48128
+if argv and argv[0] == "--rows":
+    M = int(argv[1])
+    argv = argv[2:]
+extra = []
+while argv and argv[0] == "--case":          # --case m n k epilogue
+    extra.append(("case", int(argv[1]), int(argv[2]), int(argv[3]), int(argv[4])))
+    argv = argv[5:]
+for path in argv:
     h = C.CDLL(path)
     h.oasr_gemm_bf16.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_int32, vp]
     libs.append((Path(path).stem.replace("abl_gemm_", ""), h))
 # the first case is repeated at the end: the first launches of a fresh process on a fresh machine can run slow
-cases = [("ffn_up swish", 48128, 4096, 1024, 1), ("ffn_down resid", 48128, 1024, 4096, 3),
-         ("qkv bias", 48128, 3072, 1024, 0), ("out resid", 48128, 1024, 1024, 3), ("glu", 48128, 2048, 1024, 2),
-         ("ctc f32", 48128, 256, 1024, 4), ("fproj", 48128, 1024, 192, 4),
-         ("ffn_up again", 48128, 4096, 1024, 1), ("glu again", 48128, 2048, 1024, 2)]
+cases = [("ffn_up swish", M, 4096, 1024, 1), ("ffn_down resid", M, 1024, 4096, 3),
+         ("qkv bias", M, 3072, 1024, 0), ("out resid", M, 1024, 1024, 3), ("glu", M, 2048, 1024, 2),
+         ("ctc f32", M, 256, 1024, 4), ("fproj", M, 1024, 192, 4),
+         ("ffn_up again", M, 4096, 1024, 1), ("glu again", M, 2048, 1024, 2)]
+if extra:
+    cases = extra
 dev = torch.device("cuda")
 st = torch.cuda.current_stream().cuda_stream
 for name, m, n, k, epi in cases:
