@@ -129,6 +129,7 @@ __device__ __forceinline__ float sum16(float v) {
 //          writes and the column-wise reads of 16 lanes touch 16 different banks
 //   obuf   the 16 x 80 log-mel values of a unit, so that they leave as whole 128-byte lines (rows of 320
 //          bytes written 64 bytes at a time would be fetched and written back twice by the memory side)
+constexpr int kBufferWord3 = 0x00020000;   // raw buffer descriptor, 32-bit data format (gfx9 family)
 constexpr int kIterFrames = 16;
 constexpr int kIterSpan = (kIterFrames - 1) * OASR_FRAME_HOP + OASR_FRAME_LEN;   // 2800 samples
 constexpr int kTileDw = 16 * 16;                                                  // dwords per frame tile
@@ -343,17 +344,27 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
             // occupy registers during the transforms; the zero the compiler cannot see keeps the loads here
             bf16x8 wfh[4], wfl[4];
             {
+                // buffer addressing (scalar descriptor + 16 lane bytes): a per-lane 64-bit pointer kept across the
+                // unit loop was one of the values the register allocator spilled at 128 registers
                 int opaque = 0;
                 asm volatile("" : "+s"(opaque));
-                const uint32_t* fr = &tab->mel_frag[task0 + opaque][0][lane][0];
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<uint32_t*>(&tab->mel_frag[task0 + opaque][0][0][0]), 0, 4 * 2 * 64 * 16, kBufferWord3);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int tt = t < ntask ? t : 0;
-                    wfh[t] = *reinterpret_cast<const bf16x8*>(fr + tt * 512);
-                    wfl[t] = *reinterpret_cast<const bf16x8*>(fr + tt * 512 + 256);
+                    wfh[t] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, tt * 2048, 0));
+                    wfl[t] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, tt * 2048 + 1024, 0));
                 }
             }
             __syncthreads();   // every wave is done with its transpose tiles: the buffer becomes the power spectrum
+            // From here on the lane's LDS and buffer offsets are derived from a copy of the lane number that the
+            // compiler cannot see through: otherwise it computes all of them once, in front of the unit loop, and at
+            // 128 registers keeps eight of them in scratch memory (9 MB of spill stores per launch, every
+            // work-group's, counted as HBM writes; recomputing them costs a dozen integer instructions per unit).
+            int lane_here = lane;
+            asm volatile("" : "+v"(lane_here));
+            const int q = lane_here >> 4, c = lane_here & 15;
             // ---- bf16 high part and remainder to LDS: K-step s holds bins 32 s + c (slot 2 c) and
             //      32 s + 16 + c (slot 2 c + 1) of this lane ----------------------------------------------------
             {
@@ -426,7 +437,11 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
             // ---- per-block (mean, M2) partials over the block's frames, two passes over the kept values --
             // v0: frames 0..15 of the block, v1: frames 16..31 (absent when the block ends in its first half)
             const float inv = 1.0f / (float)nfb;
+            int lane_here = lane;                  // as above: offsets recomputed here, not kept across the loop
+            asm volatile("" : "+v"(lane_here));
+            const int q = lane_here >> 4, c = lane_here & 15;
             const bool ok0 = c < nfb, ok1 = 16 + c < nfb;
+            const __amdgpu_buffer_rsrc_t stats_rs = __builtin_amdgcn_make_buffer_rsrc(my_stats, 0, OASR_NMEL * 2 * 4, kBufferWord3);
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 if (a == 1 && wave != 0) break;
@@ -437,10 +452,9 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
                     const float mean = sum16((ok0 ? v0 : 0.f) + (ok1 ? v1 : 0.f)) * inv;
                     const float d0 = ok0 ? v0 - mean : 0.f, d1 = ok1 ? v1 - mean : 0.f;
                     const float m2 = sum16(d0 * d0 + d1 * d1);
-                    if (c == 0) {
-                        const int j = 16 * blk + 4 * q + r;
-                        my_stats[j * 2 + 0] = mean;
-                        my_stats[j * 2 + 1] = m2;
+                    if (c == 0) {   // (mean, M2) of filter j = 16 blk + 4 q + r -> my_stats[2 j], [2 j + 1]
+                        typedef __attribute__((ext_vector_type(2))) float f32x2s;
+                        __builtin_amdgcn_raw_buffer_store_b64((f32x2s){mean, m2}, stats_rs, q * 32, (16 * blk + r) * 8, 0);
                     }
                 }
             }
