@@ -544,20 +544,69 @@ __device__ __forceinline__ void wait_vmcnt_slices(int slices) {   // s_waitcnt v
     }
 }
 
-template <int EPI, int TN>
+// One producer wave of the stream kernel: NA pieces (16 rows x one K slice, 1 KiB) of A from row a_row and NW pieces
+// of W from row w_row per slice, to lds_a / lds_w inside ring slot (slice % RING); RING - 1 slices are requested
+// before the first barrier, then one per barrier.  barrier_it is passed with this wave's pieces of slices <= it + 1
+// in LDS; slice it + RING - 1 then goes into the slot of slice it - 1, whose fragments the consumers had in registers
+// before they arrived at barrier_it (the slot of slice `it` itself may still be being read: slice 0 is read after
+// barrier_0).
+// The weight pieces are requested non-temporal (aux 2): at this size every step streams the whole model from HBM
+// (0.58 GB, more than the memory-side cache holds), a piece is used by the few row tiles of one utterance and never
+// again, and the hint shortens the copy's issue-to-landed time - which, with a fixed number of bytes in flight, is
+// the rate.  Step of one 30 s utterance 2.63 -> 2.57 ms; the same hint on the activation pieces (re-read by every
+// column tile) costs 13 %, and on the weights of the kernel above 4 %.
+template <int NA, int NW, int RING, int SLOT>
+__device__ __forceinline__ void stream_producer(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, int64_t a_row,
+                                                int64_t w_row, int64_t K, int nph, int flags, char* lds_a, char* lds_w, int lane) {
+    const bool w_packed = flags & OASR_GEMM_W_PACKED, a_packed = flags & OASR_GEMM_A_PACKED;
+    const uint32_t lane_off =
+        (uint32_t)(((lane >> 2) * K + (((lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3)) << 3)) * 2);
+    const int64_t piece_stride = 16 * K * 2;
+    const uint32_t lane_off_w = w_packed ? (uint32_t)lane * 16 : lane_off;
+    const int64_t piece_stride_w = w_packed ? (int64_t)nph * 1024 : piece_stride;
+    const int w_step = w_packed ? 1024 : BK * 2;
+    const uint32_t lane_off_a = a_packed ? (uint32_t)lane * 16 : lane_off;
+    const int64_t piece_stride_a = a_packed ? (int64_t)nph * 1024 : piece_stride;
+    const int a_step = a_packed ? 1024 : BK * 2;
+    const char* st_a = reinterpret_cast<const char*>(A) + (a_packed ? (a_row >> 4) * (int64_t)nph * 1024 : a_row * K * 2);
+    const char* st_w = reinterpret_cast<const char*>(W) + (w_packed ? (w_row >> 4) * (int64_t)nph * 1024 : w_row * K * 2);
+    auto issue = [&](int p) {
+        const int slot = (p % RING) * SLOT;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(st_a + i * piece_stride_a + lane_off_a), (lds_void*)(lds_a + slot + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(st_w + i * piece_stride_w + lane_off_w), (lds_void*)(lds_w + slot + i * 1024), 16, 0, 2);
+        st_a += a_step;
+        st_w += w_step;
+    };
+    int issued = 0;
+    for (; issued < RING - 1 && issued < nph; ++issued) issue(issued);
+    for (int it = 0; it < nph; ++it) {
+        const int ahead = issued - it - 2;      // everything issued but the newest `ahead` slices must have landed
+        wait_vmcnt_slices<NA + NW>(ahead < 0 ? 0 : ahead);
+        OASR_RAW_BARRIER();
+        if (issued < nph) issue(issued++);
+    }
+}
+
+template <int EPI, int TM, int TN>
 __global__ __launch_bounds__(512) void gemm_bf16_stream_kernel(const uint16_t* __restrict__ A,
                                                                const uint16_t* __restrict__ W,
                                                                const float* __restrict__ bias, const float* resid,
                                                                void* C, int64_t N, int64_t K, float alpha,
                                                                int tiles_m, int n_tiles, int flags) {
-    // consumer waves: CWM x CWN, a wave owns (16 MI) x 64 of the tile
-    constexpr int TM = 128, CWN = TN / 64, CWM = 4 / CWN, kConsumers = 4;
+    // Eight waves: consumers CWM x CWN, a wave owning (16 MI) x 64 of the tile, then the producers.
+    //   128 x 128: consumers 2 x 2 (64 x 64 each), 4 producers of 4 pieces;  128 x 64: 4 x 1 (32 x 64), 4 producers of 3;
+    //   96 x 64: 3 x 1 (32 x 64), 5 producers of 2 - the tile for 1536 rows x 1024 columns (one 30 s utterance):
+    //   16 x 16 = 256 equal work-groups, one per CU, where 128 x 64 tiles give 192.
+    constexpr int CWN = TN / 64, CWM = TM == 96 ? 3 : 4 / CWN, kConsumers = CWM * CWN, kProducers = 8 - kConsumers;
     constexpr int MI = TM / (16 * CWM);
-    constexpr int kRingSlots = kStreamRing;                            // 8 x 16 or 12 KiB
+    constexpr int kRingSlots = kStreamRing;                            // 8 slots of 16, 12 or 10 KiB
     constexpr int kSlotA = TM * BK * 2, kSlot = (TM + TN) * BK * 2;
-    constexpr int kAPieces = TM / 64, kWPieces = TN / 64;              // pieces (16 rows) per producer wave and slice
-    constexpr int kCopies = kAPieces + kWPieces;                       // copies per producer wave and slice
-    const bool w_packed = flags & OASR_GEMM_W_PACKED, a_packed = flags & OASR_GEMM_A_PACKED, c_packed = flags & OASR_GEMM_C_PACKED;
+    static_assert(MI * 16 * CWM == TM && kProducers == (TM == 96 ? 5 : 4), "tile does not divide over the waves");
+    const bool c_packed = flags & OASR_GEMM_C_PACKED;
     __shared__ __attribute__((aligned(1024))) char smem[kRingSlots * kSlot + kConsumers * kEpiSlab];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -572,55 +621,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_stream_kernel(const uint16_t* _
     const int nph = (int)(K / BK);
 
     if (wave >= kConsumers) {
-        // ---- producers: wave pw copies A pieces kAPieces pw .. and W pieces kWPieces pw .. of every slice
+        // ---- producers.  Tiles of 128 rows: wave pw copies A pieces 2 pw, 2 pw + 1 and W piece(s) (TN / 64) pw .. of
+        // every slice; 96 x 64: waves 0-2 copy two A pieces each, waves 3-4 two W pieces each.  The loop of a
+        // producer is straight-line code for its piece counts (a per-copy choice between the operands inside one
+        // generic loop ran the single-utterance step 5-11 % slower).
         const int pw = wave - kConsumers;
-        const uint32_t lane_off =
-            (uint32_t)(((lane >> 2) * K + (((lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3)) << 3)) * 2);
-        const int64_t piece_stride = 16 * K * 2;
-        const uint32_t lane_off_w = w_packed ? (uint32_t)lane * 16 : lane_off;
-        const int64_t piece_stride_w = w_packed ? (int64_t)nph * 1024 : piece_stride;
-        const int w_step = w_packed ? 1024 : BK * 2;
-        const uint32_t lane_off_a = a_packed ? (uint32_t)lane * 16 : lane_off;
-        const int64_t piece_stride_a = a_packed ? (int64_t)nph * 1024 : piece_stride;
-        const int a_step = a_packed ? 1024 : BK * 2;
-        const int64_t a_row = m0 + pw * (16 * kAPieces), w_row = n0 + pw * (16 * kWPieces);
-        const char* st_a = reinterpret_cast<const char*>(A) + (a_packed ? (a_row >> 4) * (int64_t)nph * 1024 : a_row * K * 2);
-        const char* st_w = reinterpret_cast<const char*>(W) + (w_packed ? (w_row >> 4) * (int64_t)nph * 1024 : w_row * K * 2);
-        auto issue = [&](int p) {
-            char* slot = smem + (p % kRingSlots) * kSlot;
-            // The weight pieces are requested non-temporal (aux 2): at this size every step streams the whole model
-            // from HBM (0.58 GB, more than the memory-side cache holds), a piece is used by the few row tiles of one
-            // utterance and never again, and the hint shortens the copy's issue-to-landed time - which, with a fixed
-            // number of bytes in flight, is the rate.  Step of one 30 s utterance 2.63 -> 2.57 ms; the same hint on the
-            // activation pieces (re-read by every column tile) costs 13 %, and on the weights of the kernel above 4 %.
-#ifndef OASR_STREAM_AUX_A
-#define OASR_STREAM_AUX_A 0
-#endif
-#ifndef OASR_STREAM_AUX_W
-#define OASR_STREAM_AUX_W 2
-#endif
-#pragma unroll
-            for (int i = 0; i < kAPieces; ++i)
-                __builtin_amdgcn_global_load_lds((gbl_void*)(st_a + i * piece_stride_a + lane_off_a),
-                                                 (lds_void*)(slot + (pw * kAPieces + i) * 1024), 16, 0, OASR_STREAM_AUX_A);
-#pragma unroll
-            for (int i = 0; i < kWPieces; ++i)
-                __builtin_amdgcn_global_load_lds((gbl_void*)(st_w + i * piece_stride_w + lane_off_w),
-                                                 (lds_void*)(slot + kSlotA + (pw * kWPieces + i) * 1024), 16, 0, OASR_STREAM_AUX_W);
-            st_a += a_step;
-            st_w += w_step;
-        };
-        int issued = 0;
-        for (; issued < kRingSlots - 1 && issued < nph; ++issued) issue(issued);
-        for (int it = 0; it < nph; ++it) {
-            // slices <= it + 1 must have landed: everything issued but the newest (issued - it - 2) slices
-            const int ahead = issued - it - 2;
-            wait_vmcnt_slices<kCopies>(ahead < 0 ? 0 : ahead);
-            OASR_RAW_BARRIER();
-            // slice it + kRingSlots - 1 goes into the slot of slice it - 1, whose fragments the consumers had in
-            // registers before they arrived at barrier_it (the slot of slice `it` itself may still be being read:
-            // slice 0 is read after barrier_0)
-            if (issued < nph) issue(issued++);
+        if (TM == 96) {
+            if (pw < 3)
+                stream_producer<2, 0, kRingSlots, kSlot>(A, W, m0 + pw * 32, 0, K, nph, flags, smem + pw * 2048, nullptr, lane);
+            else
+                stream_producer<0, 2, kRingSlots, kSlot>(A, W, 0, n0 + (pw - 3) * 32, K, nph, flags, nullptr,
+                                                         smem + kSlotA + (pw - 3) * 2048, lane);
+        } else {
+            constexpr int kW = TN / 64;
+            stream_producer<2, kW, kRingSlots, kSlot>(A, W, m0 + pw * 32, n0 + pw * (16 * kW), K, nph, flags, smem + pw * 2048,
+                                                      smem + kSlotA + pw * kW * 1024, lane);
         }
         return;
     }
@@ -734,15 +749,23 @@ static int gemm_bf16_launch(const uint16_t* a, const uint16_t* w, const float* b
         // tiles: 21.5 us against 26.8 on 128 x 128 and 20.0 on 256 x 128 tiles here; QKV 16.8 against 23.0 and
         // 18.9) and stays in charge.
         const int64_t t128 = (m / 128) * (n / 128);
-        const int tile_m = 128, tile_n = t128 <= OASR_STREAM_TN_CUT ? 64 : 128;
+        const int tile_n = t128 <= OASR_STREAM_TN_CUT ? 64 : 128;
+        // 96-row tiles when they divide m and still number at most one per CU: more, smaller, equal work-groups
+        // (1536 x 1024, the shapes of one 30 s utterance: 256 work-groups where 128-row tiles give 192)
+#ifndef OASR_STREAM_96
+#define OASR_STREAM_96 1
+#endif
+        const int tile_m = OASR_STREAM_96 && tile_n == 64 && m % 96 == 0 && (m / 96) * (n / 64) <= kMaxCUs ? 96 : 128;
         const int tm = (int)(m / tile_m), tn = (int)(n / tile_n), nt = tm * tn;
         hipStream_t st = (hipStream_t)stream;
 #define OASR_LAUNCH_STREAM(E)                                                                                              \
     do {                                                                                                                   \
-        if (tile_n == 64)                                                                                                  \
-            hipLaunchKernelGGL((gemm_bf16_stream_kernel<E, 64>), dim3((unsigned)nt), dim3(512), 0, st, a, w, bias, resid, c, n, k, alpha, tm, nt, flags);  \
+        if (tile_m == 96)                                                                                                  \
+            hipLaunchKernelGGL((gemm_bf16_stream_kernel<E, 96, 64>), dim3((unsigned)nt), dim3(512), 0, st, a, w, bias, resid, c, n, k, alpha, tm, nt, flags);   \
+        else if (tile_n == 64)                                                                                             \
+            hipLaunchKernelGGL((gemm_bf16_stream_kernel<E, 128, 64>), dim3((unsigned)nt), dim3(512), 0, st, a, w, bias, resid, c, n, k, alpha, tm, nt, flags);  \
         else                                                                                                               \
-            hipLaunchKernelGGL((gemm_bf16_stream_kernel<E, 128>), dim3((unsigned)nt), dim3(512), 0, st, a, w, bias, resid, c, n, k, alpha, tm, nt, flags); \
+            hipLaunchKernelGGL((gemm_bf16_stream_kernel<E, 128, 128>), dim3((unsigned)nt), dim3(512), 0, st, a, w, bias, resid, c, n, k, alpha, tm, nt, flags); \
     } while (0)
         switch (epilogue) {
             case OASR_EPI_BIAS_BF16: OASR_LAUNCH_STREAM(OASR_EPI_BIAS_BF16); break;

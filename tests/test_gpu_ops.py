@@ -248,17 +248,18 @@ def test_gemm_bias_with_several_tiles_per_work_group_and_short_k(m, n, k, epi):
     torch.testing.assert_close(c.cpu().double(), ref, atol=2e-2 if epi == 0 else 1e-4, rtol=1e-2 if epi == 0 else 1e-5)
 
 
-@pytest.mark.parametrize("shape", [(4096, 768, 4096, 512), (8192, 768, 1024, 512), (8192, 1536, 1024, 4096),
-                                   (8192, 2304, 2048, 2048), (4096, 1536, 4096, 1024)])
+@pytest.mark.parametrize("shape", [(4096, 768, 4096, 512), (8192, 1024, 1024, 512), (8192, 768, 1024, 512),
+                                   (8192, 1536, 1024, 4096), (8192, 2304, 2048, 2048), (4096, 1536, 4096, 1024)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 def test_gemm_small_tiles_equal_large_tiles_bit_for_bit(epi, shape):
-    """Problems with fewer than 128 tiles of 256 x 256 run on 128-row tiles: the producer / consumer kernel with
-    128 x 128 tiles (first shape) or 128 x 64 tiles (second and third: 128 x 128 tiles would occupy at most half
-    of the CUs), or - more 128 x 128 tiles than CUs, the last two shapes - the kernel whose waves both copy and
-    multiply, two work-groups to a CU.  All kernels perform the same operations per output element, so the first
-    rows of a large problem equal a small problem on those rows exactly (this is what keeps an utterance's states
-    independent of the batch it is in, and why K is never split over work-groups).  The third and fifth shapes
-    are the FFN down- and up-projection of a single 30 s utterance (128 and 32 K slices)."""
+    """Problems with fewer than 128 tiles of 256 x 256 run on smaller tiles: the producer / consumer kernel with
+    128 x 128 tiles (first shape), 128 x 64 tiles (second: 128 x 128 tiles would occupy at most half of the CUs)
+    or 96 x 64 tiles (third and fourth: the row count is a multiple of 96), or - more 128 x 128 tiles than CUs,
+    the last two shapes - the kernel whose waves both copy and multiply, two work-groups to a CU.  All kernels
+    perform the same operations per output element, so the first rows of a large problem equal a small problem
+    on those rows exactly (this is what keeps an utterance's states independent of the batch it is in, and why K
+    is never split over work-groups).  The fourth and sixth shapes are the FFN down- and up-projection of a
+    single 30 s utterance (128 and 32 K slices)."""
     H = _lib()
     g = torch.Generator().manual_seed(epi)
     m_big, m_small, n, k = shape

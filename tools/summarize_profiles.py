@@ -59,11 +59,27 @@ for mode, cmd in (("graph", "python3 bench.py --steps 10 --warmup 3 --no-cpu-bas
         if last:
             md += ["bench line of this run:", "", "```", last[-1], "```", ""]
 
+# BASELINE configs[1] and configs[4]: kernel statistics and the bench line of the profiled run
+for mode, title, cmd in (("b1", "BASELINE configs[1]: one 30 s utterance", "python3 bench.py --batch 1 --steps 30 --warmup 5 --no-cpu-baseline"),
+                         ("g7b_fp8", "BASELINE configs[4]: 7B geometry, fp8 projections, batch 8 x 30 s",
+                          "python3 bench.py --model G7B --batch 8 --fp8 --steps 10 --warmup 3 --no-cpu-baseline")):
+    table, _ = stats_table(mode)
+    if table:
+        log = out / ("%s_stats_%s.log" % (tag, mode))
+        last = [l for l in log.read_text().splitlines() if l.startswith("{")]
+        md += ["## %s - `rocprofv3 --kernel-trace --stats -- %s`" % (title, cmd), "", table, ""]
+        if last:
+            (prof / ("%s_bench_%s.json" % (tag, mode))).write_text(last[-1] + "\n")
+            md += ["bench line of this run (also `%s_bench_%s.json`):" % (tag, mode), "", "```", last[-1], "```", ""]
+
 traffic = {}
 KB = 1024.0
 for kind, substr, key, shape, algo in (
         ("gemm", "gemm_bf16_kernel<1", "gemm_bf16_kernel<1>", "48128x4096x1024",
          48128 * 1024 * 2 + 4096 * 1024 * 2 + 4096 * 4 + 48128 * 4096 * 2),
+        # the fp8 FFN up-projection of BASELINE configs[4]: e4m3 operands, bf16 output, row scales and bias
+        ("gemm8", "gemm_fp8_kernel<1", "gemm_fp8_kernel<1>", "12288x16384x4096",
+         12288 * 4096 + 16384 * 4096 + (12288 + 2 * 16384) * 4 + 12288 * 16384 * 2),
         ("logmel", "logmel_kernel", "logmel_kernel", "32x480000", 32 * (480000 * 4 + 2998 * 80 * 4)),
         # the two small kernels after it: per-utterance statistics (32 x 8 partial blocks x 160 floats in, 160 out)
         # and normalise + stack (log-mel in, stacked float32 features [1504][160] out)
