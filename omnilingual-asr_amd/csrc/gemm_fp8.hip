@@ -110,6 +110,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[4][2], const float (&sam)
                 for (int r2 = 0; r2 < 2; ++r2)
                     rnext[h][r2] = *reinterpret_cast<const float4*>(resid + index_of(i + 1, h, r2));
         }
+        u32x2 pk16[2][2];   // bf16 epilogues: this lane's 4 outputs of (half h, row pair r2), kept until both halves exist
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             // rows 16 hf .. 16 hf + 15 of m-tile im are held by the lanes with ((lane & 31) >> 4) == hf
@@ -148,8 +149,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[4][2], const float (&sam)
                             const f32x2 lo = swish2((f32x2){o.x, o.y}), hi = swish2((f32x2){o.z, o.w});
                             o = make_float4(lo[0], lo[1], hi[0], hi[1]);
                         }
-                        const u32x2 pk = {cvt_pk_bf16(o.x, o.y), cvt_pk_bf16(o.z, o.w)};
-                        __builtin_nontemporal_store(pk, reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(C) + index_of(i, h, r2)));
+                        pk16[h][r2] = (u32x2){cvt_pk_bf16(o.x, o.y), cvt_pk_bf16(o.z, o.w)};
                     } else {
                         if (EPI == OASR_EPI_RESIDUAL_F32) {
                             const float4 r = rcur[h][r2];
@@ -160,6 +160,26 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[4][2], const float (&sam)
                                                     reinterpret_cast<u32x4*>(reinterpret_cast<float*>(C) + index_of(i, h, r2)));
                     }
                 }
+            }
+        }
+        if (EPI == OASR_EPI_BIAS_BF16 || EPI == OASR_EPI_BIAS_SWISH_BF16) {
+            // A lane holds columns 4 c .. 4 c + 3 (c = lane & 7) of both 32-column halves: 8-byte pieces, which stored
+            // as they are leave as half cache lines (measured: 1.21 bytes written per byte of output, and twice the
+            // store instructions).  Neighbouring lanes swap one piece each, so that an even lane has columns
+            // 4 c .. 4 c + 7 of the first half and the odd lane next to it the same columns of the second half:
+            // 16-byte stores, 8 whole 128-byte lines per instruction.
+            const bool odd = rchunk & 1;
+#pragma unroll
+            for (int r2 = 0; r2 < 2; ++r2) {
+                const u32x2 send = odd ? pk16[0][r2] : pk16[1][r2];
+                u32x2 recv;
+                recv[0] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send[0], 0xB1, 0xf, 0xf, false);   // lane ^ 1
+                recv[1] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send[1], 0xB1, 0xf, 0xf, false);
+                const u32x4 v = odd ? (u32x4){recv[0], recv[1], pk16[1][r2][0], pk16[1][r2][1]}
+                                    : (u32x4){pk16[0][r2][0], pk16[0][r2][1], recv[0], recv[1]};
+                uint16_t* dst = reinterpret_cast<uint16_t*>(C) + (mbase + i * 16 + rrow + 8 * r2) * N + nbase + (odd ? 32 : 0) +
+                                (rchunk >> 1) * 8;
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst));
             }
         }
         if (EPI == OASR_EPI_RESIDUAL_F32) {
