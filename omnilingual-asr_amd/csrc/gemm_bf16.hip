@@ -715,6 +715,12 @@ __global__ __launch_bounds__(256) void gemm_pack_w_kernel(const uint16_t* __rest
 
 using namespace oasr;
 
+#define OASR_TRY_GEMM(call)             \
+    do {                                \
+        const int rc_ = (call);         \
+        if (rc_ != OASR_OK) return rc_; \
+    } while (0)
+
 static int gemm_bf16_launch(const uint16_t* a, const uint16_t* w, const float* bias, const float* resid, void* c,
                             int64_t m, int64_t n, int64_t k, float alpha, int32_t epilogue, void* stream,
                             int flags) {
@@ -800,6 +806,31 @@ static int gemm_bf16_launch(const uint16_t* a, const uint16_t* w, const float* b
 #undef OASR_LAUNCH_SMALL
         OASR_CHECK_LAUNCH("gemm (small tiles)");
         return OASR_OK;
+    }
+#ifndef OASR_SPLIT_TAIL
+#define OASR_SPLIT_TAIL 1
+#endif
+    if (OASR_SPLIT_TAIL && tiles > kMaxCUs) {
+        // 256 work-groups walk the tiles in rounds; a last round with few tiles leaves most CUs idle for a whole
+        // tile time (six utterances, 36 row tiles x 16: 2.25 rounds cost 3, and ran slower than eight utterances).
+        // Rows are independent, so when whole rounds can be cut off at a row-tile boundary and the rest is less than
+        // 5/8 of a round, the rest runs as a problem of its own on the small-tile kernels above (same arithmetic per
+        // output element: the rows' results do not change).
+        const int64_t tn = n / BN, tm = m / BM;
+        int64_t g = tn, h = kMaxCUs;                // row tiles per whole round = 256 / gcd(tn, 256)
+        while (h) { const int64_t t = g % h; g = h; h = t; }
+        const int64_t per_round = kMaxCUs / g, full = tm / per_round * per_round, rest = tm - full;
+        if (full > 0 && rest > 0 && rest * tn * 8 <= kMaxCUs * 5) {
+            OASR_TRY_GEMM(gemm_bf16_launch(a, w, bias, resid, c, full * BM, n, k, alpha, epilogue, stream, flags));
+            const int64_t row = full * BM;
+            const bool f32_out = epilogue == OASR_EPI_RESIDUAL_F32 || epilogue == OASR_EPI_BIAS_F32;
+            const int64_t c_cols = epilogue == OASR_EPI_GLU_BF16 ? n / 2 : n;
+            // packed matrices keep a 16-row group's pieces together: [row group][K slice] of 1 KiB
+            const uint16_t* a2 = a + row * k;       // the same element offset in both layouts (row is a multiple of 16)
+            char* c2 = reinterpret_cast<char*>(c) + row * c_cols * (f32_out ? 4 : 2);
+            const float* r2 = resid ? resid + row * c_cols : nullptr;
+            return gemm_bf16_launch(a2, w, bias, r2, c2, rest * BM, n, k, alpha, epilogue, stream, flags);
+        }
     }
     // one persistent work-group per CU; the grid is a multiple of 8 so that every XCD gets the same
     // number of work-groups

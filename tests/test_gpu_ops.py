@@ -528,3 +528,42 @@ def test_gemm_packed_output_then_packed_input(m, n, k, epi):
     assert L.oasr_gemm_bf16_ex(a.data_ptr(), w.data_ptr(), bias.data_ptr(), None, c_pk.data_ptr(), m, n, k, 1.0,
                                H.EPI_BIAS_F32, H.GEMM_C_PACKED, _stream()) != 0   # float32 outputs have no packed form
     assert L.oasr_gemm_bf16_ex(a.data_ptr(), w.data_ptr(), bias.data_ptr(), None, c_pk.data_ptr(), m, n, k, 1.0, epi, 8, _stream()) != 0
+
+
+@pytest.mark.parametrize("n,k,epi,flags_c", [(4096, 1024, 1, 1), (4096, 1024, 3, 0), (2048, 1024, 2, 0), (4096, 256, 0, 0)])
+def test_gemm_with_a_short_last_round_equals_the_rows_of_a_whole_number_of_rounds(n, k, epi, flags_c):
+    """36 row tiles (six 30 s utterances) by 16 or 8 column tiles are 2.25 or 1.125 rounds of the 256 persistent
+    work-groups: the launcher cuts the last four row tiles off and runs them on the small-tile kernels.  48 row tiles
+    are whole rounds and run undivided; their first 9216 rows must equal the divided problem bit for bit - with the
+    product written packed and read back as a packed left operand as well, whose offsets the cut has to get right."""
+    H = _lib()
+    L = H.lib()
+    m_big, m = 12288, 9216
+    g = torch.Generator().manual_seed(n + k + epi)
+    a = _bf(torch.randn((m_big, k), generator=g)).cuda()
+    w = _bf(torch.randn((n, k), generator=g) / math.sqrt(k)).cuda()
+    bias = None if epi == 2 else torch.randn((n,), generator=g).cuda()
+    n_out = n // 2 if epi == 2 else n
+    resid = torch.randn((m_big, n_out), generator=g).cuda() if epi == 3 else None
+    flags = H.GEMM_C_PACKED if flags_c else 0
+    outs = []
+    for rows in (m_big, m):
+        c = torch.zeros((rows, n_out), dtype=torch.float32 if epi == 3 else torch.bfloat16, device="cuda")
+        H.check(L.oasr_gemm_bf16_ex(a.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(),
+                                    None if resid is None else resid.data_ptr(), c.data_ptr(), rows, n, k, 0.5, epi, flags, _stream()))
+        outs.append(c)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][:m], outs[1])
+    assert outs[1][m - 1024:].float().abs().max() > 0
+    if flags_c:
+        # the packed product as the left operand of a second product, cut the same way (36 x 16 tiles again)
+        w2 = _bf(torch.randn((4096, n), generator=g) / math.sqrt(n)).cuda()
+        row_major = torch.zeros((m, n), dtype=torch.bfloat16, device="cuda")
+        H.check(L.oasr_gemm_bf16_ex(a.data_ptr(), w.data_ptr(), bias.data_ptr(), None, row_major.data_ptr(), m, n, k, 0.5, epi, 0, _stream()))
+        second = []
+        for amat, fl in ((row_major, 0), (outs[1], H.GEMM_A_PACKED)):
+            c2 = torch.zeros((m, 4096), dtype=torch.bfloat16, device="cuda")
+            H.check(L.oasr_gemm_bf16_ex(amat.data_ptr(), w2.data_ptr(), None, None, c2.data_ptr(), m, 4096, n, 1.0, 0, fl, _stream()))
+            second.append(c2)
+        torch.cuda.synchronize()
+        assert torch.equal(second[0], second[1])
