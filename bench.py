@@ -199,7 +199,7 @@ def kernel_rooflines(engine, batch: int, t_pad: int, pcm, nv, hidden) -> dict:
     up_shape = "%dx%dx%d" % (rows, f, d)
     lm_shape = "%dx%d" % (batch, pcm.shape[1])
     main = entry(kern + "<BIAS_SWISH>", ms_up, 2.0 * rows * f * d, up_shape)
-    main["traffic"] = measured_traffic("gemm_bf16_kernel<1>", up_shape) if not fp8 else None
+    main["traffic"] = measured_traffic("gemm_fp8_kernel<1>" if fp8 else "gemm_bf16_kernel<1>", up_shape)
     attn_e = entry("attention_relkey_kernel<%d>" % g.head_dim, ms_attn, attn_flops,
                    "%dx%dx%dx%d" % (batch, g.n_heads, t_valid, g.head_dim))
     attn_e["peak"], attn_e["frac"] = MFMA_BF16_PEAK_TFLOPS, round(attn_e["achieved"] / MFMA_BF16_PEAK_TFLOPS, 4)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Launch one fp8 GEMM shape a few times (profiling target for rocprofv3 --pmc): gemm8_one.py [M N K EPI].
 Weights packed, as the encoder keeps them; default: the FFN up-projection of BASELINE configs[4]
-(batch 8 x 30 s at d = 4096: 12032 rows, rounded up to 12288)."""
+(batch 8 x 30 s at d = 4096: 12032 rows)."""
 import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -9,7 +9,7 @@ sys.path.insert(0, str(ROOT / "omnilingual-asr_amd"))
 import torch
 from omnilingual_asr import _hip
 L = _hip.lib()
-m, n, k, epi = 12288, 16384, 4096, 1
+m, n, k, epi = 12032, 16384, 4096, 1
 if len(sys.argv) > 1:
     m, n, k, epi = [int(v) for v in sys.argv[1:5]]
 dev = torch.device("cuda")

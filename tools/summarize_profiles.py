@@ -78,8 +78,8 @@ for kind, substr, key, shape, algo in (
         ("gemm", "gemm_bf16_kernel<1", "gemm_bf16_kernel<1>", "48128x4096x1024",
          48128 * 1024 * 2 + 4096 * 1024 * 2 + 4096 * 4 + 48128 * 4096 * 2),
         # the fp8 FFN up-projection of BASELINE configs[4]: e4m3 operands, bf16 output, row scales and bias
-        ("gemm8", "gemm_fp8_kernel<1", "gemm_fp8_kernel<1>", "12288x16384x4096",
-         12288 * 4096 + 16384 * 4096 + (12288 + 2 * 16384) * 4 + 12288 * 16384 * 2),
+        ("gemm8", "gemm_fp8_kernel<1", "gemm_fp8_kernel<1>", "12032x16384x4096",
+         12032 * 4096 + 16384 * 4096 + (12032 + 2 * 16384) * 4 + 12032 * 16384 * 2),
         ("logmel", "logmel_kernel", "logmel_kernel", "32x480000", 32 * (480000 * 4 + 2998 * 80 * 4)),
         # the two small kernels after it: per-utterance statistics (32 x 8 partial blocks x 160 floats in, 160 out)
         # and normalise + stack (log-mel in, stacked float32 features [1504][160] out)
