@@ -297,8 +297,8 @@ int oasr_flac_decode_range(const uint8_t* data, int64_t size, int64_t first, int
  * interleaved float32 samples, nominally in [-1, 1) (not clipped); `diagnostics` may be NULL, else 5 words:
  * audio frames, bytes stepped over while searching for frames, granules whose spectrum ran past its stated length,
  * frames or granules delivered as silence (damaged, or their bit reservoir missing), stuffing bits.  Streams of 4096
- * frames or more are decoded by up to 16 host threads on frame ranges (each starts 12 frames early and discards those:
- * the samples equal an in-order decode); OASR_MP3_THREADS in the environment overrides the count.
+ * frames or more are decoded by up to 16 host threads on frame ranges (each starts early enough that the frames it
+ * discards hold the whole bit reservoir its first kept frame reaches back into: the samples equal an in-order decode); OASR_MP3_THREADS in the environment overrides the count.
  * Free-format streams and Layers I / II return OASR_EINVAL. */
 int oasr_mp3_info(const uint8_t* data, int64_t size, int32_t* sample_rate, int32_t* channels,
                   int64_t* samples_per_channel);
@@ -310,13 +310,43 @@ int oasr_mp3_decode_mono(const uint8_t* data, int64_t size, float* out, int64_t 
                          int64_t* diagnostics);
 /* A stream opened once (its frames found and counted) and decoded by sample ranges, so that a caller can work on
  * one part of a long file while the next is being decoded: oasr_mp3_decode_mono_range writes the samples
- * [first, first + count) of what oasr_mp3_decode_mono would deliver, bit for bit (each range starts 12 frames early
- * and discards those).  `data` must stay readable until oasr_mp3_close; ranges may be decoded from several threads at once. */
+ * [first, first + count) of what oasr_mp3_decode_mono would deliver, bit for bit (each range starts early enough to
+ * rebuild the bit reservoir and filter history, and discards those frames).  `data` must stay readable until oasr_mp3_close; ranges may be decoded from several threads at once. */
 typedef struct oasr_mp3_stream oasr_mp3_stream;
 int oasr_mp3_open(const uint8_t* data, int64_t size, oasr_mp3_stream** stream, int32_t* sample_rate, int32_t* channels,
                   int64_t* samples_per_channel);
 int oasr_mp3_decode_mono_range(const oasr_mp3_stream* stream, int64_t first, int64_t count, float* out);
 void oasr_mp3_close(oasr_mp3_stream* stream);
+
+/* Ogg Vorbis decode on the host: `.ogg` is among the upload types the reference lists (ref gemini_pipeline.py:106-118
+ * MIME table, workflows/wav2elan_web/app.py:76-77; the reference forwards the bytes to its remote model).  The first
+ * Vorbis stream of an Ogg file (page checksums verified; other multiplexed streams stepped over; Opus, Speex or FLAC in
+ * Ogg named in the error): Vorbis I with floor 1, residues 0 / 1 / 2, channel coupling, both block sizes; floor 0
+ * returns OASR_EINVAL.  A file that ends inside a page is decoded up to the last whole page.  The sample count follows
+ * the granule positions (start and end trimming).  oasr_vorbis_info parses the headers and walks the packets' first
+ * bytes only.  oasr_vorbis_decode writes interleaved float32 samples (not clipped), oasr_vorbis_decode_mono the channel
+ * mean (formed in double, rounded once).  `threads`: 0 = up to 16 host threads on packet ranges for long streams (a
+ * packet depends on the one before it only, so each range starts one packet early; the samples are the same for any
+ * count), n > 0 = at most n. */
+int oasr_vorbis_info(const uint8_t* data, int64_t size, int32_t* sample_rate, int32_t* channels,
+                     int64_t* samples_per_channel);
+int oasr_vorbis_decode(const uint8_t* data, int64_t size, float* out, int64_t capacity_per_channel,
+                       int64_t* written_per_channel, int32_t threads);
+int oasr_vorbis_decode_mono(const uint8_t* data, int64_t size, float* out, int64_t capacity, int64_t* written,
+                            int32_t threads);
+/* A stream opened once and decoded by sample ranges - what a rank of a process group uses to read only its own shard
+ * of chunks, and what lets a caller work on one part of a long file while the next is decoded:
+ * oasr_vorbis_decode_mono_range writes the samples [first, first + count) of what oasr_vorbis_decode_mono delivers, bit
+ * for bit.  The stream keeps its own copy of the packets: `data` may be released after oasr_vorbis_open.  Ranges may
+ * be decoded from several threads at once. */
+typedef struct oasr_vorbis_stream oasr_vorbis_stream;
+int oasr_vorbis_open(const uint8_t* data, int64_t size, oasr_vorbis_stream** stream, int32_t* sample_rate,
+                     int32_t* channels, int64_t* samples_per_channel);
+int oasr_vorbis_decode_mono_range(const oasr_vorbis_stream* stream, int64_t first, int64_t count, float* out);
+void oasr_vorbis_close(oasr_vorbis_stream* stream);
+/* Test diagnostic: per audio packet, the bits left unread when its residue decode ended (-1: it ran into the end of
+ * the packet).  An encoder writes no more than it needs, so with the right code books the figure stays below 8. */
+int oasr_vorbis_packet_tails(const uint8_t* data, int64_t size, int32_t* tails, int64_t capacity, int64_t* packets);
 
 /* LayerNorm (optionally followed by Swish) straight to e4m3 rows + per-row scale: byte-identical to
  * oasr_layernorm(out_bf16=1) followed by oasr_quant_fp8_rows, without the intermediate bf16 matrix.

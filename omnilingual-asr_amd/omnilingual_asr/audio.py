@@ -1,12 +1,12 @@
-"""Audio ingest: WAV, AIFF/AIFF-C, FLAC and MP3 decode, down-mix and polyphase resampling to 16 kHz mono
+"""Audio ingest: WAV, AIFF/AIFF-C, FLAC, MP3 and Ogg Vorbis decode, down-mix and polyphase resampling to 16 kHz mono
 float32.
 
 The reference hands the encoded file to its remote model and uses ffprobe/ffmpeg only for duration
 and slicing (ref:src/omnilingual_asr/models/inference/gemini_pipeline.py:222-310).  Here the host
-decodes the audio itself: PCM containers in this module, FLAC and MPEG Layer III by the native decoders in
-liboasr_hip.so (`oasr_flac_decode`, `oasr_mp3_decode`).  The file type is taken from its first bytes, not its
-name.  The other lossy formats the reference lists (:106-118: aac, ogg, m4a) need decoders this package does
-not contain and raise `UnsupportedAudioError`.
+decodes the audio itself: PCM containers in this module, FLAC, MPEG Layer III and Ogg Vorbis by the native decoders
+in liboasr_hip.so (`oasr_flac_decode`, `oasr_mp3_decode`, `oasr_vorbis_decode`).  The file type is taken from its
+first bytes, not its name.  The remaining formats the reference lists (:106-118: aac, m4a) and other codecs in an
+Ogg container (Opus, Speex) need decoders this package does not contain and raise `UnsupportedAudioError`.
 """
 
 from __future__ import annotations
@@ -71,7 +71,7 @@ def read_wav(path) -> tuple[np.ndarray, int]:
     data = path.read_bytes()
     if data[:4] not in _RIFF_MAGICS:
         raise UnsupportedAudioError(
-            f"cannot decode '{path.suffix}' audio: WAV, AIFF, FLAC and MP3 input is supported")
+            f"cannot decode '{path.suffix}' audio: WAV, AIFF, FLAC, MP3 and Ogg Vorbis input is supported")
     fmt = payload = None
     for cid, body in _riff_chunks(data):
         if cid == b"fmt ":
@@ -236,7 +236,8 @@ def wav_duration(path) -> float:
 
 def audio_duration(path) -> float:
     """Duration in seconds without decoding, for every container `read_audio` decodes (WAV data chunk, AIFF
-    COMM chunk, FLAC STREAMINFO; MP3: its frame headers are counted); raises on anything unreadable."""
+    COMM chunk, FLAC STREAMINFO; MP3: its frame headers are counted; Ogg Vorbis: its pages are walked for the block
+    sizes and granule positions); raises on anything unreadable."""
     with open(path, "rb") as f:
         head = f.read(1 << 16)
     if head[:4] in _RIFF_MAGICS and not _looks_like_mp3(head, path):
@@ -257,6 +258,9 @@ def audio_duration(path) -> float:
         rate, total = x >> 44, x & ((1 << 36) - 1)
         if rate > 0 and total > 0:
             return total / float(rate)
+    if head[:4] == b"OggS":
+        rate, _, total = vorbis_info(path)
+        return total / float(rate)
     if _looks_like_mp3(head, path):
         rate, _, total = mp3_info(path)
         return total / float(rate)
@@ -656,6 +660,97 @@ def is_mp3(path) -> bool:
         return _looks_like_mp3(f.read(12), path)
 
 
+def is_ogg(path) -> bool:
+    with open(path, "rb") as f:
+        return f.read(4) == b"OggS"
+
+
+def _vorbis_call(path, mono: bool):
+    import ctypes as C
+
+    from . import _hip
+    buf = np.fromfile(path, dtype=np.uint8)
+    rate, channels, total = C.c_int32(), C.c_int32(), C.c_int64()
+    L = _hip.lib()
+    try:
+        _hip.check(L.oasr_vorbis_info(buf.ctypes.data, buf.size, C.byref(rate), C.byref(channels), C.byref(total)),
+                   "oasr_vorbis_info")
+        if mono is None:
+            return None, int(rate.value), int(channels.value), int(total.value)
+        out = np.zeros((total.value,) if mono else (total.value, channels.value), dtype=np.float32)
+        written = C.c_int64()
+        fn = L.oasr_vorbis_decode_mono if mono else L.oasr_vorbis_decode
+        _hip.check(fn(buf.ctypes.data, buf.size, out.ctypes.data, total.value, C.byref(written), 0), "oasr_vorbis_decode")
+    except _hip.OasrError as e:
+        raise UnsupportedAudioError(str(e)) from e
+    return out[: written.value], int(rate.value), int(channels.value), int(total.value)
+
+
+def vorbis_info(path) -> tuple[int, int, int]:
+    """(sample_rate, channels, samples per channel as the granule positions state them) of an Ogg Vorbis file."""
+    _, rate, channels, total = _vorbis_call(path, None)
+    return rate, channels, total
+
+
+def read_ogg(path) -> tuple[np.ndarray, int]:
+    """Decode the first Vorbis stream of an Ogg file with the native decoder -> (float32 [frames, channels], rate);
+    not clipped.  Opus, Speex and FLAC in an Ogg container are refused by name."""
+    out, rate, _, _ = _vorbis_call(path, False)
+    return out, rate
+
+
+def read_ogg_mono(path) -> tuple[np.ndarray, int]:
+    """(float32 [frames], rate): `read_ogg` with the channels averaged inside the decoder (mean formed in double)."""
+    out, rate, _, _ = _vorbis_call(path, True)
+    return out, rate
+
+
+class VorbisStream:
+    """An Ogg Vorbis file opened once (headers parsed, packets placed on the sample axis) and decoded by sample
+    ranges: `read_mono(first, count)` returns the samples [first, first + count) of what `read_ogg_mono` delivers, bit
+    for bit.  Ranges may be read from several threads at once."""
+
+    def __init__(self, path):
+        import ctypes as C
+
+        from . import _hip
+        self._handle = None
+        self._lib = _hip.lib()
+        buf = np.fromfile(path, dtype=np.uint8)      # the opened stream keeps its own copy of the packets
+        rate, channels, total = C.c_int32(), C.c_int32(), C.c_int64()
+        self._handle = C.c_void_p()
+        try:
+            _hip.check(self._lib.oasr_vorbis_open(buf.ctypes.data, buf.size, C.byref(self._handle), C.byref(rate),
+                                                  C.byref(channels), C.byref(total)), "oasr_vorbis_open")
+        except _hip.OasrError as e:
+            self._handle = None
+            raise UnsupportedAudioError(str(e)) from e
+        self.rate, self.channels, self.samples = int(rate.value), int(channels.value), int(total.value)
+
+    def read_mono(self, first: int, count: int) -> np.ndarray:
+        from . import _hip
+        if not self._handle:
+            raise ValueError("the stream is closed")
+        out = np.zeros((int(count),), dtype=np.float32)
+        _hip.check(self._lib.oasr_vorbis_decode_mono_range(self._handle, int(first), int(count), out.ctypes.data),
+                   "oasr_vorbis_decode_mono_range")
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None):
+            self._lib.oasr_vorbis_close(self._handle)
+        self._handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        self.close()
+
+
 def read_audio(path) -> tuple[np.ndarray, int]:
     """Decode by content: (float32 [frames, channels], sample_rate)."""
     with open(path, "rb") as f:
@@ -666,10 +761,12 @@ def read_audio(path) -> tuple[np.ndarray, int]:
         return read_aiff(path)
     if head[:4] == b"fLaC" or head[:3] == b"ID3" and Path(path).suffix.lower() == ".flac":
         return read_flac(path)
+    if head[:4] == b"OggS":
+        return read_ogg(path)
     if _looks_like_mp3(head, path):
         return read_mp3(path)
     raise UnsupportedAudioError(
-        f"cannot decode '{Path(path).suffix}' audio: WAV, AIFF, FLAC and MP3 input is supported")
+        f"cannot decode '{Path(path).suffix}' audio: WAV, AIFF, FLAC, MP3 and Ogg Vorbis input is supported")
 
 
 def load_audio_16k(path, resampler=None, keep_int16: bool = False) -> np.ndarray:
@@ -684,7 +781,9 @@ def load_audio_16k(path, resampler=None, keep_int16: bool = False) -> np.ndarray
         fast = read_wav_pcm16_mono(path) if is_riff else None
         if fast is not None and fast[1] == TARGET_RATE:
             return fast[0]
-    if is_mp3(path):
+    if is_ogg(path):
+        mono, rate = read_ogg_mono(path)
+    elif is_mp3(path):
         mono, rate = read_mp3_mono(path)
     else:
         x, rate = read_audio(path)

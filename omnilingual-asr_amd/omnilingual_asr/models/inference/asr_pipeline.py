@@ -272,8 +272,10 @@ class _Spans:
 
 
 class _Mp3Spans(_Spans):
-    def __init__(self, path):
-        self._stream = _audio.Mp3Stream(path)
+    """An MP3 or an Ogg Vorbis file: the native decoders deliver any sample range as mono float32."""
+
+    def __init__(self, path, opener=None):
+        self._stream = (opener or _audio.Mp3Stream)(path)
         self.rate, self.samples = self._stream.rate, self._stream.samples
 
     def read(self, lo: int, hi: int):
@@ -482,10 +484,13 @@ class GeminiASRPipeline:
                     # the converted signal stays on the device when the chunk loop can gather batches there
                     return self.engine.pcm_to_16k(samples, channels, rate, sample_bytes, bits,
                                                   on_device=hasattr(self.engine, "submit"))
-        if hasattr(self.engine, "resample_16k") and hasattr(self.engine, "submit") and _audio.is_mp3(audio_path):
-            mono, rate = _audio.read_mp3_mono(audio_path)          # host threads decode; the rate conversion runs on
-            with self._engine_lock:                                # the device and the 16 kHz signal stays there
-                return self.engine.resample_16k(mono, rate)
+        if hasattr(self.engine, "resample_16k") and hasattr(self.engine, "submit"):
+            lossy = (_audio.read_ogg_mono if _audio.is_ogg(audio_path) else
+                     _audio.read_mp3_mono if _audio.is_mp3(audio_path) else None)
+            if lossy is not None:
+                mono, rate = lossy(audio_path)                     # host threads decode; the rate conversion runs on
+                with self._engine_lock:                            # the device and the 16 kHz signal stays there
+                    return self.engine.resample_16k(mono, rate)
         resampler = None
         if hasattr(self.engine, "resample_16k"):
             def resampler(mono, rate):
@@ -511,14 +516,15 @@ class GeminiASRPipeline:
         return merge_results([self._transcribe_chunk(r, word_timestamps) for r in records])
 
     def _open_span_source(self, audio_path):
-        """A reader that hands over any sample range of the file without the rest, or None: an MP3 (always), and -
-        under a process group, where a rank needs only its shard - an integer PCM WAV or a FLAC whose samples have
-        to be converted (a mono 16-bit WAV at 16 kHz is memory-mapped and sliced as it is)."""
+        """A reader that hands over any sample range of the file without the rest, or None: an MP3 or an Ogg Vorbis
+        file (always), and - under a process group, where a rank needs only its shard - an integer PCM WAV or a FLAC
+        whose samples have to be converted (a mono 16-bit WAV at 16 kHz is memory-mapped and sliced as it is)."""
         eng = self.engine
-        if _audio.is_mp3(audio_path):
+        ogg = _audio.is_ogg(audio_path)
+        if ogg or _audio.is_mp3(audio_path):
             if self.process_group is None and not (hasattr(eng, "submit") and hasattr(eng, "resample_16k")):
                 return None                     # one process, host engine: nothing to overlap the decode with
-            return _Mp3Spans(audio_path)
+            return _Mp3Spans(audio_path, _audio.VorbisStream if ogg else None)
         if self.process_group is None:
             return None
         mapped = _audio.map_wav_pcm(audio_path)

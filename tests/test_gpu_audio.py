@@ -296,3 +296,34 @@ def test_progress_steps_of_the_segmented_path_arrive_around_the_work(golden_dir)
     t = {s: at for s, _, at in steps}
     assert t["uploading"] < t["transcribing"] < min(stamps["submit"])
     assert max(stamps["collect"]) < t["processing"] < t["done"]
+
+
+@pytest.mark.parametrize("rate", [44100, 16000])
+def test_long_ogg_vorbis_in_segments_equals_the_one_pass_path(tmp_path, rate):
+    """An Ogg Vorbis file goes the MP3's way: host threads decode it to mono, the device converts the rate, and a long
+    file is taken in segments whose decode overlaps the device's work (`_encode_streamed` on a `VorbisStream`).  Same
+    segments, texts and word times as decoding the whole file first.  Stereo stream from the test writer
+    (tests/vorbis_tools.py), its packets repeated to 20 s."""
+    import vorbis_tools as vt
+    from omnilingual_asr import Pipeline, audio
+
+    rng = np.random.default_rng(3)
+    n = rate * 2
+    t = np.arange(n) / rate
+    x = (0.2 * np.sin(2 * np.pi * 170.0 * t) * (np.sin(2 * np.pi * 1.3 * t) > 0))[:, None] + 0.05 * rng.standard_normal((n, 2))
+    enc = vt.encode(x, vt.Config(channels=2, rate=rate, pattern="LLSL", seed=3, residue_type=2, coupled=True))
+    path = tmp_path / "long.ogg"
+    path.write_bytes(vt.repeat_stream(enc, 10))
+    total = audio.vorbis_info(path)[2]
+    assert audio.audio_duration(path) == total / rate > 19.0
+    pipe = Pipeline(model="GTINY", seed=4, batch_size=2, chunk_seconds=2.5, min_chunking_seconds=2.5).gemini
+    streamed = pipe._encode_streamed(path, True)
+    whole = pipe._encode_file(pipe._load_audio(path), True)
+    assert streamed is not None and len(streamed.segments) == len(whole.segments) >= 8
+    for a, b in zip(streamed.segments, whole.segments):
+        assert (a.start, a.end, a.text, a.words) == (b.start, b.end, b.text, b.words)
+    assert any(s.text for s in whole.segments)
+    assert pipe.transcribe_chunked(path).segments == pipe._encode_streamed(path, False).segments
+    # the device path's 16 kHz signal against the host's converter on the same decode
+    mono, r = audio.read_ogg_mono(path)
+    np.testing.assert_allclose(pipe._load_audio(path).cpu().numpy(), audio.resample_poly(mono, r, 16000), atol=2e-6)

@@ -282,11 +282,12 @@ def test_two_ranks_decode_only_their_shards_of_an_mp3():
     assert len(lines) == 2 and all("equal to the unsharded result: True" in l for l in lines), lines
 
 
-def test_two_ranks_read_only_their_shards_of_a_stereo_wav_and_a_flac():
-    """The same for uncompressed and lossless input: a 48 kHz 16-bit stereo WAV (memory-mapped; a rank uploads and
-    converts only the bytes of its shard, on the device) and the reference's FLAC upload (a rank decodes only the
-    frames that cover its shard).  Each of the two ranks reads about half of the source samples and the merged
-    result equals the unsharded one, which loads the file whole (tools/sharded_mp3.py wav flac)."""
+def test_two_ranks_read_only_their_shards_of_a_stereo_wav_a_flac_and_an_ogg():
+    """The same for uncompressed and lossless input, and for Ogg Vorbis: a 48 kHz 16-bit stereo WAV (memory-mapped; a
+    rank uploads and converts only the bytes of its shard, on the device), the reference's FLAC upload (a rank decodes
+    only the frames that cover its shard) and a 22.05 kHz stereo Vorbis stream from the test writer (a rank decodes
+    only the packets that cover its shard).  Each of the two ranks reads about half of the source samples and the
+    merged result equals the unsharded one, which loads the file whole (tools/sharded_mp3.py wav flac ogg)."""
     import socket
     import subprocess
     import sys
@@ -297,11 +298,11 @@ def test_two_ranks_read_only_their_shards_of_a_stereo_wav_and_a_flac():
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(root / "tools" / "sharded_mp3.py"), "wav", "flac"]
+           "--master-port", str(port), str(root / "tools" / "sharded_mp3.py"), "wav", "flac", "ogg"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=str(root))
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
     lines = [l for l in out.stdout.splitlines() if l.startswith("rank ")]
-    assert len(lines) == 4 and all("equal to the unsharded result: True" in l for l in lines), lines
+    assert len(lines) == 6 and all("equal to the unsharded result: True" in l for l in lines), lines
     for l in lines:
         pct = int(l.rsplit("(", 1)[1].split()[0])
         assert 40 <= pct <= 60, l

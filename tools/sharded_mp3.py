@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Rehearsal of sharded ingest: run under torch.distributed.run with N ranks (gloo; the ranks may share GPU 0).
 Every rank calls the public long-audio entry on the same file; each reads and converts only the samples of its own
-shard of chunks (MP3 frames, FLAC frames, the bytes of a memory-mapped WAV), the records cross in the one all-gather,
+shard of chunks (MP3 frames, FLAC frames, Vorbis packets, the bytes of a memory-mapped WAV), the records cross in the one all-gather,
 and every rank checks the merged result against a pipeline without a process group, which loads the file whole.
-Usage: python -m torch.distributed.run --nproc-per-node 2 tools/sharded_mp3.py [mp3|wav|flac ...]   (default: mp3)"""
+Usage: python -m torch.distributed.run --nproc-per-node 2 tools/sharded_mp3.py [mp3|wav|flac|ogg ...]   (default: mp3)"""
 import os, struct, sys, tempfile
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -38,6 +38,20 @@ for kind in kinds:
         path, total = golden / "reference_demo_40s.mp3", 1531 * 1152 - 576 - 1190
     elif kind == "flac":
         path, total = golden / "reference_upload.flac", 312060
+    elif kind == "ogg":
+        sys.path.insert(0, str(ROOT / "tests"))
+        import vorbis_tools as vt
+        path = Path(tempfile.gettempdir()) / ("oasr_sharded_%d.ogg" % os.getppid())
+        rng = np.random.default_rng(5)
+        n = 22050 * 2
+        t = np.arange(n) / 22050.0
+        x = (0.2 * np.sin(2 * np.pi * 170.0 * t) * (np.sin(2 * np.pi * 1.3 * t) > 0))[:, None] + 0.05 * rng.standard_normal((n, 2))
+        enc = vt.encode(x, vt.Config(channels=2, rate=22050, pattern="LLSL", seed=5, residue_type=2, coupled=True))
+        if rank == 0:
+            path.write_bytes(vt.repeat_stream(enc, 20))
+        dist.barrier()
+        from omnilingual_asr import audio as _audio
+        total = _audio.vorbis_info(path)[2]
     else:
         path = Path(tempfile.gettempdir()) / ("oasr_sharded_%d.wav" % os.getppid())
         total = int(40.0 * 48000)
@@ -59,7 +73,7 @@ for kind in kinds:
     print("rank %d of %d, %s: %d segments, equal to the unsharded result: %s, read %d of %d source samples (%.0f %%)"
           % (rank, world, kind, len(got.segments), same, share, total, 100.0 * share / total), flush=True)
     dist.barrier()
-    if kind == "wav" and rank == 0:
+    if kind in ("wav", "ogg") and rank == 0:
         path.unlink()
 flag = torch.tensor([1 if ok_all else 0])
 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
