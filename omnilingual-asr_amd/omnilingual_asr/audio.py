@@ -261,7 +261,7 @@ def audio_duration(path) -> float:
     if head[:4] == b"OggS":
         rate, _, total = vorbis_info(path)
         return total / float(rate)
-    if _looks_like_mp3(head, path):
+    if _looks_like_mp3(head, path) or _is_mp3_behind_junk(head, path):
         rate, _, total = mp3_info(path)
         return total / float(rate)
     raise UnsupportedAudioError("no duration in the header")
@@ -655,9 +655,26 @@ class Mp3Stream:
         self.close()
 
 
+_OTHER_MAGICS = _RIFF_MAGICS + (b"FORM", b"fLaC", b"OggS")
+
+
+def _is_mp3_behind_junk(head: bytes, path) -> bool:
+    """A file whose first bytes name no container at all may still be an MP3 with padding or a foreign tag block (APE,
+    a run of zeros) in front of its first frame: the native frame scan steps over such bytes and accepts a stream only
+    on two chained frame headers, so it is asked."""
+    if head[:4] in _OTHER_MAGICS or head[4:8] == b"ftyp":
+        return False
+    try:
+        mp3_info(path)
+        return True
+    except UnsupportedAudioError:
+        return False
+
+
 def is_mp3(path) -> bool:
     with open(path, "rb") as f:
-        return _looks_like_mp3(f.read(12), path)
+        head = f.read(12)
+    return _looks_like_mp3(head, path) or _is_mp3_behind_junk(head, path)
 
 
 def is_ogg(path) -> bool:
@@ -763,7 +780,7 @@ def read_audio(path) -> tuple[np.ndarray, int]:
         return read_flac(path)
     if head[:4] == b"OggS":
         return read_ogg(path)
-    if _looks_like_mp3(head, path):
+    if _looks_like_mp3(head, path) or _is_mp3_behind_junk(head, path):
         return read_mp3(path)
     raise UnsupportedAudioError(
         f"cannot decode '{Path(path).suffix}' audio: WAV, AIFF, FLAC, MP3 and Ogg Vorbis input is supported")

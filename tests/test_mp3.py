@@ -296,10 +296,22 @@ def test_damage_is_contained(tmp_path):
     p.write_bytes(data[: 9 * fb + 100])
     y, _ = audio.read_mp3(p)
     assert y.shape[0] == 9 * 1152 and np.array_equal(y[: 8 * 1152], clean[: 8 * 1152])
+    # padding or a foreign tag block in front of the first frame: the type is found by the frame scan, not by byte 0
+    for lead in (bytes(700), b"APETAGEX" + bytes(range(256)) * 3):
+        q = tmp_path / "lead.bin"
+        q.write_bytes(lead + data)
+        assert audio.is_mp3(q) and audio.audio_duration(q) == clean.shape[0] / 44100.0
+        y, rate = audio.read_audio(q)
+        assert rate == 44100 and np.array_equal(y, clean)
+        assert audio.load_audio_16k(q).shape[0] == -(-clean.shape[0] * 160 // 441)
     # not an MP3 at all
     p.write_bytes(b"\xff\xfb" + bytes(200))
     with pytest.raises(audio.UnsupportedAudioError):
         audio.read_mp3(p)
+    p.write_bytes(bytes(5000))
+    assert not audio.is_mp3(p)
+    with pytest.raises(audio.UnsupportedAudioError):
+        audio.read_audio(p)
 
 
 def test_mp3_inside_a_wave_container(tmp_path):
