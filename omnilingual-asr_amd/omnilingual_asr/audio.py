@@ -382,6 +382,8 @@ def read_aiff(path) -> tuple[np.ndarray, int]:
         x = _g711_table(kind.decode().lower())[np.frombuffer(raw, dtype=np.uint8)]
     elif kind in (b"NONE", b"twos", b"sowt"):
         order = "<" if kind == b"sowt" else ">"
+        if not 1 <= bits <= 32:
+            raise UnsupportedAudioError(f"unsupported AIFF sample width {bits}")
         n = len(raw) // width
         if width == 1:
             v = np.frombuffer(raw, dtype=np.int8).astype(np.int32)

@@ -327,3 +327,15 @@ def test_flac_sample_ranges_equal_the_whole_decode(golden_dir, tmp_path, monkeyp
         for first, count in ((0, 6 * 4096), (4000, 200), (8192, 4096), (24575, 1)):
             got = fs.read_pcm(first, count).reshape(-1, 2)
             assert np.array_equal(got.astype(np.int64), want24[first: first + count])
+
+
+def test_aiff_that_states_no_sample_width_is_refused(tmp_path):
+    """A COMM chunk with 0 (or more than 32) bits per sample: refused, not divided by."""
+    for bits in (0, 40, -8):
+        comm = struct.pack(">hIh", 1, 4, bits) + b"\x40\x0e\xac\x44" + bytes(6)
+        ssnd = struct.pack(">II", 0, 0) + bytes(16)
+        body = b"AIFF" + b"COMM" + struct.pack(">I", len(comm)) + comm + b"SSND" + struct.pack(">I", len(ssnd)) + ssnd
+        p = tmp_path / "z.aiff"
+        p.write_bytes(b"FORM" + struct.pack(">I", len(body)) + body)
+        with pytest.raises(audio.UnsupportedAudioError):
+            audio.read_audio(p)

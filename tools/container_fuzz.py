@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fuzz of the container readers (host code only): small valid files of every kind the package decodes - WAV (16- and
-24-bit PCM, mu-law, IMA ADPCM), AIFF, FLAC, MP3 - are damaged at random (header bytes overwritten, truncation, bit
+24-bit PCM, mu-law, IMA ADPCM), AIFF, FLAC, MP3, Ogg Vorbis - are damaged at random (header bytes overwritten, truncation, bit
 flips anywhere, size fields replaced by extreme values) and loaded through `audio.load_audio_16k` under a 12 GB
 address-space limit.  Every file must either decode or be refused with UnsupportedAudioError / OasrError; any other
 exception, a MemoryError (a header obeyed instead of checked) or a load of more than 1.5 s is reported.
@@ -42,6 +42,7 @@ seeds = {
     "x.aiff": aiff(2, 16, 22050, rng.integers(-3000, 3000, 4000, dtype=np.int16).astype(">i2").tobytes()),
     "x.flac": (gold / "reference_upload.flac").read_bytes(),
     "x.mp3": (gold / "reference_demo_40s.mp3").read_bytes()[:40000],
+    "x.ogg": (gold / "mathjax_invalid_keypress.ogg").read_bytes(),
 }
 for name, blob in seeds.items():          # every seed decodes as it is (and the library is loaded before timing starts)
     p = os.path.join(tempfile.gettempdir(), "oasr_fz_" + name)
