@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Soak run of the public call: many files of random length, rate, width and channel count (integer PCM WAVs, and
-every fifth file an MP3 from the test encoder: mono / stereo / mid-side, 8 - 48 kHz) in sequence through one
+"""Soak run of the public call: many files of random length, rate, width and channel count (integer PCM WAVs, every
+fifth file an MP3 from the test encoder: mono / stereo / mid-side, 8 - 48 kHz, and every seventh an Ogg Vorbis file
+from the test writer: mono / coupled stereo, both block sizes) in sequence through one
 pipeline (graph capture per shape bucket, buffer eviction, device-resident and host-resident sample paths), each
 checked against a second pipeline that runs eager launches on freshly decoded host samples.  Usage: soak.py [files]"""
 import struct, sys, tempfile, os
@@ -39,6 +40,18 @@ for k in range(files):
         with open(path, "wb") as f:
             f.write(data)
         width, seconds = 0, frames * spf / rate
+    elif k % 7 == 6:        # an Ogg Vorbis file, a few seconds repeated up to ~60 s
+        import vorbis_tools
+        base = min(int(seconds * rate), 2 * rate)
+        pcm = 0.15 * rng.standard_normal((max(base, 64), channels))
+        enc = vorbis_tools.encode(pcm if channels > 1 else pcm[:, 0], vorbis_tools.Config(
+            channels=channels, rate=rate, pattern=str(rng.choice(["L", "LLSL", "SSL"])), seed=k, trim_end=True,
+            residue_type=2 if channels == 2 else int(rng.integers(2)), coupled=channels == 2,
+            book_kind=str(rng.choice(["lattice", "table"]))))
+        times = max(1, min(30, int(seconds * rate) // max(base, 64)))
+        with open(path, "wb") as f:
+            f.write(vorbis_tools.repeat_stream(enc, times) if times > 1 else enc.data)
+        width, seconds = 0, audio.audio_duration(path)
     elif width == 1:
         payload = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
     elif width == 2:
