@@ -321,23 +321,43 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
 #pragma unroll
             for (int n2 = 0; n2 < 16; ++n2) a[n2].im = tile[c * 32 + (n2 ^ c)];
             fft16(a, y1);                                    // y1[k2] = Z[c + 16 k2]
-            // ---- real-FFT split and power: X[k] = E[k] + W512^k O[k], E / O from Z[k] and Z[256 - k] ------
-            float pw[16];
+            // ---- real-FFT split and power.  X[k] = E + T and X[256 - k] = conj(E - T) with E, O from the pair
+            //      (Z[k], Z[256 - k]) and T = W512^k O: one pair gives both bins.  256 - (c + 16 k2) = (16 - c) + 16 (15 - k2),
+            //      so the lanes of columns c and 16 - c share their pairs: each takes the pairs of its own k2 = 0..7
+            //      (partner's k2 = 15..8, eight values fetched instead of sixteen) and ends with the powers of its own
+            //      column's k2 = 0..7 and of the partner column's k2 = 8..15.  Columns 0 and 8 are their own partners
+            //      (column 0 pairs k2 with 16 - k2: its k2 = 8 is the self-paired bin 128, |X|^2 = 4 |Z|^2 under
+            //      the 1/2 that rides on the window). --------------------------------------------------------------
+            float pw[16];   // [0..7]: column c, k2 = 0..7; [8..15]: column (16 - c) & 15, k2 = 8..15
             {
                 const int partner = (lane & 48) | ((16 - c) & 15);
+                cpx far[8];   // the partner's y1[8 .. 15]
 #pragma unroll
-                for (int j = 0; j < 16; ++j) a[j] = cpx{__shfl(y1[j].re, partner, 64), __shfl(y1[j].im, partner, 64)};
+                for (int j = 0; j < 8; ++j) far[j] = cpx{__shfl(y1[8 + j].re, partner, 64), __shfl(y1[8 + j].im, partner, 64)};
+                float pm[8];
 #pragma unroll
-                for (int k2 = 0; k2 < 16; ++k2) {
-                    // 256 - (c + 16 k2) = (16 - c) + 16 (15 - k2) for c > 0, 16 (16 - k2) for c = 0
-                    const cpx zm = c == 0 ? a[(16 - k2) & 15] : a[15 - k2];
-                    const cpx zk = y1[k2];
-                    const float2 w = twp[k2 * 16 + c];
+                for (int j = 0; j < 8; ++j) {
+                    // column 0: partner index 16 - j (its own registers, j = 0: itself); otherwise 15 - j
+                    cpx zm = far[7 - j];
+                    if (j == 0) {
+                        if (c == 0) zm = y1[0];
+                    } else if (c == 0) {
+                        zm = far[8 - j];
+                    }
+                    const cpx zk = y1[j];
+                    const float2 w = twp[j * 16 + c];
                     const float er = zk.re + zm.re, ei = zk.im - zm.im;        // E (the 1/2 is in the window)
                     const float orr = zk.im + zm.im, oi = zm.re - zk.re;       // O
-                    const float xr = er + w.x * orr - w.y * oi;
-                    const float xi = ei + w.x * oi + w.y * orr;
-                    pw[k2] = xr * xr + xi * xi;
+                    const float tr = w.x * orr - w.y * oi, ti = w.x * oi + w.y * orr;
+                    const float ar = er + tr, ai = ei + ti, br = er - tr, bi = ei - ti;
+                    pw[j] = ar * ar + ai * ai;
+                    pm[j] = br * br + bi * bi;
+                }
+                const float p128 = 4.0f * (y1[8].re * y1[8].re + y1[8].im * y1[8].im);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {   // k2 = 8 + t of the partner column
+                    const float zero_col = t == 0 ? p128 : pm[8 - t];
+                    pw[8 + t] = c == 0 ? zero_col : pm[7 - t];
                 }
             }
             // this wave's mel weights, re-read every unit (L2-resident) and only now, so that they do not
@@ -365,19 +385,23 @@ __global__ __launch_bounds__(256, 4) void logmel_kernel(const float* __restrict_
             int lane_here = lane;
             asm volatile("" : "+v"(lane_here));
             const int q = lane_here >> 4, c = lane_here & 15;
-            // ---- bf16 high part and remainder to LDS: K-step s holds bins 32 s + c (slot 2 c) and
-            //      32 s + 16 + c (slot 2 c + 1) of this lane ----------------------------------------------------
+            // ---- bf16 high part and remainder to LDS: K-step s holds bins 32 s + col (slot 2 col) and
+            //      32 s + 16 + col (slot 2 col + 1); this lane has K-steps 0..3 of its own column and 4..7 of its
+            //      partner column ---------------------------------------------------------------------------------
             {
-                // frame f = 4 wave + q; dword 16 s + c of its row lives in chunk (4 s + (c >> 2)) ^ f
-                //   = 4 (s ^ wave) + ((c >> 2) ^ q): the K-step part of the swizzle is wave-uniform
+                // frame f = 4 wave + q; dword 16 s + col of its row lives in chunk (4 s + (col >> 2)) ^ f
+                //   = 4 (s ^ wave) + ((col >> 2) ^ q): the K-step part of the swizzle is wave-uniform
+                const int cp = (16 - c) & 15;
                 uint32_t* dst = pbuf + (4 * wave + q) * kPPitchDw + 4 * ((c >> 2) ^ q) + (c & 3);
+                uint32_t* dstp = pbuf + (4 * wave + q) * kPPitchDw + 4 * ((cp >> 2) ^ q) + (cp & 3);
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
                     const float pa = pw[2 * s], pb = pw[2 * s + 1];
                     const uint32_t hi = cvt_pk_bf16_rne(pa, pb);
                     const float ra = pa - __uint_as_float(hi << 16), rb = pb - __uint_as_float(hi & 0xFFFF0000u);
-                    dst[16 * (s ^ wave)] = hi;
-                    dst[kPPlaneDw + 16 * (s ^ wave)] = cvt_pk_bf16_rne(ra, rb);
+                    uint32_t* d = s < 4 ? dst : dstp;
+                    d[16 * (s ^ wave)] = hi;
+                    d[kPPlaneDw + 16 * (s ^ wave)] = cvt_pk_bf16_rne(ra, rb);
                 }
             }
             __syncthreads();   // power spectrum written; every wave has read its frames from the span
