@@ -86,19 +86,28 @@ static int lookup1_values(int entries, int dims) {
 }
 
 // ---- Ogg pages -> packets of the first Vorbis stream ----
-static uint32_t g_crc[256];
+static uint32_t g_crc[8][256];   // slice-by-8 tables of the Ogg CRC-32 (polynomial 0x04c11db7, no reflection)
 static bool g_crc_ready = false;
 static void crc_init() {
     if (g_crc_ready) return;
     for (uint32_t i = 0; i < 256; ++i) {
         uint32_t r = i << 24;
         for (int b = 0; b < 8; ++b) r = (r & 0x80000000u) ? (r << 1) ^ 0x04c11db7u : r << 1;
-        g_crc[i] = r;
+        g_crc[0][i] = r;
     }
+    for (uint32_t i = 0; i < 256; ++i)
+        for (int t = 1; t < 8; ++t) g_crc[t][i] = (g_crc[t - 1][i] << 8) ^ g_crc[0][g_crc[t - 1][i] >> 24];
     g_crc_ready = true;
 }
 static inline uint32_t crc_run(uint32_t crc, const uint8_t* p, size_t n) {
-    for (size_t i = 0; i < n; ++i) crc = (crc << 8) ^ g_crc[((crc >> 24) & 0xff) ^ p[i]];
+    while (n >= 8) {
+        const uint32_t a = crc ^ ((uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]);
+        crc = g_crc[7][a >> 24] ^ g_crc[6][(a >> 16) & 0xff] ^ g_crc[5][(a >> 8) & 0xff] ^ g_crc[4][a & 0xff] ^
+              g_crc[3][p[4]] ^ g_crc[2][p[5]] ^ g_crc[1][p[6]] ^ g_crc[0][p[7]];
+        p += 8;
+        n -= 8;
+    }
+    for (size_t i = 0; i < n; ++i) crc = (crc << 8) ^ g_crc[0][((crc >> 24) & 0xff) ^ p[i]];
     return crc;
 }
 
@@ -117,14 +126,16 @@ struct Stream {
 
 static inline uint32_t le32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
 
-static bool demux(const uint8_t* d, size_t n, Stream& s, std::string& err) {
+// `keep_bytes` false: only the packets' first byte and lengths are wanted (the sample count), so page bodies are neither
+// checked nor copied.
+static bool demux(const uint8_t* d, size_t n, Stream& s, std::string& err, bool keep_bytes = true) {
     crc_init();
     size_t pos = 0;
     bool have = false, in_packet = false, skipping = false, have_seq = false;
     uint32_t serial = 0, next_seq = 0;
     size_t cur_off = 0;
     std::string other;
-    s.body.reserve(n);
+    s.body.reserve(keep_bytes ? n : std::min<size_t>(n, 1 << 20));
     while (pos + 27 <= n) {
         if (memcmp(d + pos, "OggS", 4) != 0) {
             if (have) {
@@ -153,13 +164,15 @@ static bool demux(const uint8_t* d, size_t n, Stream& s, std::string& err) {
         uint64_t granule = 0;
         for (int i = 7; i >= 0; --i) granule = (granule << 8) | d[pos + 6 + i];
         const uint32_t ser = le32(d + pos + 14), seq = le32(d + pos + 18), crc = le32(d + pos + 22);
-        static const uint8_t zero4[4] = {0, 0, 0, 0};
-        uint32_t c = crc_run(0, d + pos, 22);
-        c = crc_run(c, zero4, 4);
-        c = crc_run(c, d + pos + 26, page_len - 26);
-        if (c != crc) {
-            err = "ogg: page checksum mismatch";
-            return false;
+        if (keep_bytes) {
+            static const uint8_t zero4[4] = {0, 0, 0, 0};
+            uint32_t c = crc_run(0, d + pos, 22);
+            c = crc_run(c, zero4, 4);
+            c = crc_run(c, d + pos + 26, page_len - 26);
+            if (c != crc) {
+                err = "ogg: page checksum mismatch";
+                return false;
+            }
         }
         const uint8_t* seg = d + pos + 27;
         const uint8_t* bp = seg + nseg;
@@ -208,7 +221,12 @@ static bool demux(const uint8_t* d, size_t n, Stream& s, std::string& err) {
                 cur_off = s.body.size();
                 in_packet = true;
             }
-            s.body.insert(s.body.end(), bp, bp + l);
+            size_t take = (size_t)l;
+            if (!keep_bytes && s.packets.size() >= 3) {   // an audio packet's mode is in its first byte
+                const size_t have = s.body.size() - cur_off;
+                take = have >= 2 ? 0 : std::min<size_t>(take, 2 - have);
+            }
+            s.body.insert(s.body.end(), bp, bp + take);
             bp += l;
             if (l < 255) {
                 s.packets.push_back(Packet{cur_off, (uint32_t)(s.body.size() - cur_off), -1, false});
@@ -990,8 +1008,8 @@ struct Plan {
     int64_t skip = 0, total = 0;   // samples dropped at the start, samples delivered
 };
 
-static bool open_stream(const uint8_t* d, size_t n, Plan& P, std::string& err) {
-    if (!demux(d, n, P.st, err)) return false;
+static bool open_stream(const uint8_t* d, size_t n, Plan& P, std::string& err, bool for_info = false) {
+    if (!demux(d, n, P.st, err, !for_info)) return false;
     if (!parse_headers(P.st, P.S, err)) return false;
     const Setup& S = P.S;
     int64_t c = 0;
@@ -1127,7 +1145,7 @@ int oasr_vorbis_info(const uint8_t* data, int64_t size, int32_t* sample_rate, in
     OASR_REQUIRE(data && size > 0 && sample_rate && channels && samples_per_channel, "vorbis_info: null pointer");
     vorbis::Plan P;
     std::string err;
-    if (!vorbis::open_stream(data, (size_t)size, P, err)) {
+    if (!vorbis::open_stream(data, (size_t)size, P, err, true)) {
         set_error("%s", err.c_str());
         return OASR_EINVAL;
     }
