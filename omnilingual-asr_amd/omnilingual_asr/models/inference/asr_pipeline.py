@@ -13,6 +13,7 @@ from __future__ import annotations
 import contextlib
 import json
 import re
+import math
 import threading
 from dataclasses import dataclass, field
 from pathlib import Path
@@ -522,8 +523,14 @@ class GeminiASRPipeline:
         eng = self.engine
         ogg = _audio.is_ogg(audio_path)
         if ogg or _audio.is_mp3(audio_path):
-            if self.process_group is None and not (hasattr(eng, "submit") and hasattr(eng, "resample_16k")):
-                return None                     # one process, host engine: nothing to overlap the decode with
+            if self.process_group is None:
+                if not (hasattr(eng, "submit") and hasattr(eng, "resample_16k")):
+                    return None                 # one process, host engine: nothing to overlap the decode with
+                # too short to be taken in segments (the caller decodes it whole, on all host threads): say so from
+                # the header walk, before the stream is opened - opening copies and checks every page of an Ogg file
+                n16 = int(math.ceil(_audio.audio_duration(audio_path) * SAMPLE_RATE))
+                if len(plan_chunks(n16, self.chunk_seconds, self.min_chunking_seconds)) < 4 * self.batch_size:
+                    return None
             return _Mp3Spans(audio_path, _audio.VorbisStream if ogg else None)
         if self.process_group is None:
             return None
