@@ -337,8 +337,8 @@ int oasr_vorbis_decode_mono(const uint8_t* data, int64_t size, float* out, int64
 /* A stream opened once and decoded by sample ranges - what a rank of a process group uses to read only its own shard
  * of chunks, and what lets a caller work on one part of a long file while the next is decoded:
  * oasr_vorbis_decode_mono_range writes the samples [first, first + count) of what oasr_vorbis_decode_mono delivers, bit
- * for bit.  The stream keeps its own copy of the packets: `data` may be released after oasr_vorbis_open.  Ranges may
- * be decoded from several threads at once. */
+ * for bit (a long range on several host threads, as the whole decode).  The stream keeps its own copy of the packets:
+ * `data` may be released after oasr_vorbis_open.  Ranges may be decoded from several threads at once. */
 typedef struct oasr_vorbis_stream oasr_vorbis_stream;
 int oasr_vorbis_open(const uint8_t* data, int64_t size, oasr_vorbis_stream** stream, int32_t* sample_rate,
                      int32_t* channels, int64_t* samples_per_channel);

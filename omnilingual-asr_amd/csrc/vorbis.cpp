@@ -1109,10 +1109,11 @@ static void packets_for(const Plan& P, int64_t first, int64_t count, size_t& a, 
     b = std::min(b, P.centre.size());
 }
 
+// packets [a, b) on up to `threads` host threads (0: as many as the machine has, at most 16; a thread per 512 packets at
+// most), each range starting one packet early
 template <bool MONO>
-static void decode_all(const Plan& P, float* out, int threads) {
-    const size_t K = P.audio.size();
-    if (K < 2 || P.total == 0) return;
+static void decode_span(const Plan& P, size_t a, size_t b, float* out, int64_t lo, int64_t hi, int threads) {
+    if (a >= b) return;
     size_t T = 1;
     if (threads <= 0) {
         const unsigned hc = std::thread::hardware_concurrency();
@@ -1120,17 +1121,24 @@ static void decode_all(const Plan& P, float* out, int threads) {
     } else {
         T = (size_t)threads;
     }
-    T = std::max<size_t>(1, std::min<size_t>(T, (K - 1) / 512 + 1));
+    T = std::max<size_t>(1, std::min<size_t>(T, (b - a) / 512 + 1));
     if (T == 1) {
-        decode_range<MONO>(P, 1, K, out, 0, P.total);
+        decode_range<MONO>(P, a, b, out, lo, hi);
         return;
     }
     std::vector<std::thread> pool;
     for (size_t t = 0; t < T; ++t) {
-        const size_t a = 1 + (K - 1) * t / T, b = 1 + (K - 1) * (t + 1) / T;
-        if (a < b) pool.emplace_back([&P, a, b, out] { decode_range<MONO>(P, a, b, out, 0, P.total); });
+        const size_t a1 = a + (b - a) * t / T, b1 = a + (b - a) * (t + 1) / T;
+        if (a1 < b1) pool.emplace_back([&P, a1, b1, out, lo, hi] { decode_range<MONO>(P, a1, b1, out, lo, hi); });
     }
     for (auto& th : pool) th.join();
+}
+
+template <bool MONO>
+static void decode_all(const Plan& P, float* out, int threads) {
+    const size_t K = P.audio.size();
+    if (K < 2 || P.total == 0) return;
+    decode_span<MONO>(P, 1, K, out, 0, P.total, threads);
 }
 
 }  // namespace vorbis
@@ -1226,7 +1234,7 @@ int oasr_vorbis_decode_mono_range(const oasr_vorbis_stream* stream, int64_t firs
     if (count == 0) return OASR_OK;
     size_t a, b;
     vorbis::packets_for(P, first, count, a, b);
-    vorbis::decode_range<true>(P, a, b, out, first, first + count);
+    vorbis::decode_span<true>(P, a, b, out, first, first + count, 0);
     return OASR_OK;
 }
 

@@ -135,6 +135,7 @@ def test_long_stream_any_thread_count_and_any_sample_range():
         assert (r.value, c.value, tot.value) == (rate, 2, one.shape[0])
         rng = np.random.default_rng(0)
         spans = [(0, 1), (0, 5000), (tot.value - 777, 777), (tot.value - 1, 1), (12345, 0)]
+        spans += [(0, tot.value), (1001, tot.value - 3003)]        # long ranges: several threads inside the call
         spans += [(int(a), int(rng.integers(1, 9000))) for a in rng.integers(0, tot.value - 9000, size=12)]
         for first, count in spans:
             got = np.full(count, np.nan, dtype=np.float32)

@@ -8,7 +8,9 @@ Usage: transcribe_e2e.py [hours [rate [channels [width]]]]   WAV of synthetic no
                                                       of noise + tone repeated
        transcribe_e2e.py mp3 [repeats]                MP3 made of the audio frames of the reference's demo recording
                                                       (40 s at 44.1 kHz joint stereo per repeat; the frame at each
-                                                      join finds another bit reservoir than it was written for)"""
+                                                      join finds another bit reservoir than it was written for)
+       transcribe_e2e.py ogg [repeats]                Ogg Vorbis from the test writer (tests/vorbis_tools.py): 4 s of 44.1 kHz
+                                                      coupled stereo per repeat (block sizes 256 / 2048), ~ 300 kbit/s"""
 import os, sys, tempfile, time, wave
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -62,6 +64,23 @@ def write_mp3(repeats: int):
     return path, total / rate / 3600.0
 
 
+def write_ogg(repeats: int):
+    sys.path.insert(0, str(ROOT / "tests"))
+    import vorbis_tools as vt
+    from omnilingual_asr import audio
+    rate = 44100
+    rng = np.random.default_rng(3)
+    n = rate * 4
+    t = np.arange(n) / rate
+    x = (0.2 * np.sin(2 * np.pi * 170.0 * t) * (np.sin(2 * np.pi * 1.3 * t) > 0))[:, None] + 0.05 * rng.standard_normal((n, 2))
+    enc = vt.encode(x, vt.Config(channels=2, rate=rate, pattern="LLLLLLLS", seed=3, residue_type=2, coupled=True))
+    path = os.path.join(tempfile.gettempdir(), "oasr_e2e.ogg")
+    with open(path, "wb") as f:
+        f.write(vt.repeat_stream(enc, repeats))
+    rate, _, total = audio.vorbis_info(path)
+    return path, total / rate / 3600.0
+
+
 def write_rf64(hours: float) -> str:
     import struct
     rate, channels = 48000, 2
@@ -87,6 +106,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "rf64":
     path = write_rf64(hours)
 elif len(sys.argv) > 1 and sys.argv[1] == "mp3":
     path, hours = write_mp3(int(sys.argv[2]) if len(sys.argv) > 2 else 180)
+elif len(sys.argv) > 1 and sys.argv[1] == "ogg":
+    path, hours = write_ogg(int(sys.argv[2]) if len(sys.argv) > 2 else 1800)
 elif len(sys.argv) > 1 and sys.argv[1] == "flac":
     path, hours = write_flac(int(sys.argv[2]) if len(sys.argv) > 2 else 400)
 else:
