@@ -86,28 +86,33 @@ static int lookup1_values(int entries, int dims) {
 }
 
 // ---- Ogg pages -> packets of the first Vorbis stream ----
-static uint32_t g_crc[8][256];   // slice-by-8 tables of the Ogg CRC-32 (polynomial 0x04c11db7, no reflection)
-static bool g_crc_ready = false;
-static void crc_init() {
-    if (g_crc_ready) return;
-    for (uint32_t i = 0; i < 256; ++i) {
-        uint32_t r = i << 24;
-        for (int b = 0; b < 8; ++b) r = (r & 0x80000000u) ? (r << 1) ^ 0x04c11db7u : r << 1;
-        g_crc[0][i] = r;
+// slice-by-8 tables of the Ogg CRC-32 (polynomial 0x04c11db7, no reflection); built once, by whichever thread comes first
+struct CrcTables {
+    uint32_t t[8][256];
+    CrcTables() {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t r = i << 24;
+            for (int b = 0; b < 8; ++b) r = (r & 0x80000000u) ? (r << 1) ^ 0x04c11db7u : r << 1;
+            t[0][i] = r;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int k = 1; k < 8; ++k) t[k][i] = (t[k - 1][i] << 8) ^ t[0][t[k - 1][i] >> 24];
     }
-    for (uint32_t i = 0; i < 256; ++i)
-        for (int t = 1; t < 8; ++t) g_crc[t][i] = (g_crc[t - 1][i] << 8) ^ g_crc[0][g_crc[t - 1][i] >> 24];
-    g_crc_ready = true;
+};
+static const uint32_t (&crc_tables())[8][256] {
+    static const CrcTables tables;   // thread-safe initialisation
+    return tables.t;
 }
 static inline uint32_t crc_run(uint32_t crc, const uint8_t* p, size_t n) {
+    const uint32_t (&g)[8][256] = crc_tables();
     while (n >= 8) {
         const uint32_t a = crc ^ ((uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]);
-        crc = g_crc[7][a >> 24] ^ g_crc[6][(a >> 16) & 0xff] ^ g_crc[5][(a >> 8) & 0xff] ^ g_crc[4][a & 0xff] ^
-              g_crc[3][p[4]] ^ g_crc[2][p[5]] ^ g_crc[1][p[6]] ^ g_crc[0][p[7]];
+        crc = g[7][a >> 24] ^ g[6][(a >> 16) & 0xff] ^ g[5][(a >> 8) & 0xff] ^ g[4][a & 0xff] ^ g[3][p[4]] ^ g[2][p[5]] ^
+              g[1][p[6]] ^ g[0][p[7]];
         p += 8;
         n -= 8;
     }
-    for (size_t i = 0; i < n; ++i) crc = (crc << 8) ^ g_crc[0][((crc >> 24) & 0xff) ^ p[i]];
+    for (size_t i = 0; i < n; ++i) crc = (crc << 8) ^ g[0][((crc >> 24) & 0xff) ^ p[i]];
     return crc;
 }
 
@@ -129,7 +134,6 @@ static inline uint32_t le32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2
 // `keep_bytes` false: only the packets' first byte and lengths are wanted (the sample count), so page bodies are neither
 // checked nor copied.
 static bool demux(const uint8_t* d, size_t n, Stream& s, std::string& err, bool keep_bytes = true) {
-    crc_init();
     size_t pos = 0;
     bool have = false, in_packet = false, skipping = false, have_seq = false;
     uint32_t serial = 0, next_seq = 0;
