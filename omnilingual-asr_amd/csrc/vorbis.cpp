@@ -386,6 +386,12 @@ static bool build_codebook(Codebook& cb, std::string& err) {
             } else {
                 int32_t c = cb.child[2 * node + bit];
                 if (c == 0) {
+                    // a complete prefix code of n words has n - 1 inner nodes, and filling the tree from the left
+                    // never holds more on the way: more means the lengths cannot come out even
+                    if (cb.child.size() / 2 > (size_t)n) {
+                        err = "vorbis: a codebook's lengths leave codewords unassigned";
+                        return false;
+                    }
                     c = (int32_t)(cb.child.size() / 2);
                     cb.child.push_back(0);
                     cb.child.push_back(0);
@@ -606,6 +612,7 @@ static bool parse_headers(const Stream& st, Setup& S, std::string& err) {
         const int framing = (int)b.get(1);
         if (b.eop || !framing) VB_FAIL("vorbis: identification header cut short");
         if (S.channels < 1 || S.rate < 1) VB_FAIL("vorbis: no channels or no sampling rate");
+        if (S.channels > 32) VB_FAIL("vorbis: more than 32 channels");
         if (e0 < 6 || e1 > 13 || e0 > e1) VB_FAIL("vorbis: block sizes outside 64 ... 8192 or out of order");
         S.bs[0] = 1 << e0;
         S.bs[1] = 1 << e1;
@@ -810,6 +817,9 @@ static void floor1_apply(const Setup& S, const Floor1& f, const int* final_y, co
 // residue of `nch` vectors of `n` values each (type 2: called with the one interleaved vector)
 static void residue_decode(const Setup& S, const Residue& r, Bits& b, float** vec, const uint8_t* skip, int nch, int n,
                            int format, std::vector<int>& classif) {
+    bool any = false;
+    for (int j = 0; j < nch; ++j) any = any || !skip[j];
+    if (!any) return;   // nothing is coded for these channels: no loop over partitions either
     const uint32_t lb = std::min<uint32_t>(r.begin, (uint32_t)n), le = std::min<uint32_t>(r.end, (uint32_t)n);
     const Codebook& cbk = S.books[r.classbook];
     const int cw = cbk.dims;
@@ -1142,7 +1152,9 @@ template <bool MONO>
 static void decode_all(const Plan& P, float* out, int threads) {
     const size_t K = P.audio.size();
     if (K < 2 || P.total == 0) return;
-    decode_span<MONO>(P, 1, K, out, 0, P.total, threads);
+    size_t a, b;
+    packets_for(P, 0, P.total, a, b);   // packets outside what the granule positions keep are not decoded at all
+    decode_span<MONO>(P, a, b, out, 0, P.total, threads);
 }
 
 }  // namespace vorbis
