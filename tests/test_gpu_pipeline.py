@@ -319,10 +319,19 @@ def test_four_threads_share_one_pipeline(tmp_path):
         p = tmp_path / f"f{i}.wav"
         _write_wav(p, seconds, rate=rate, seed=20 + i)
         paths.append(str(p))
+    # and the compressed kinds, whose native decoders run on the calling threads: an Ogg Vorbis stream from the test
+    # writer (5.6 s, coupled stereo at 22.05 kHz) and the first 40 s of the reference's MP3 recording
+    from pathlib import Path
+    import vorbis_tools as vt
+    rng = np.random.default_rng(8)
+    enc = vt.encode(0.1 * rng.standard_normal((22050 * 2, 2)), vt.Config(channels=2, rate=22050, pattern="LLSL", seed=8,
+                                                                      residue_type=2, coupled=True))
+    (tmp_path / "f6.ogg").write_bytes(vt.repeat_stream(enc, 3))
+    paths += [str(tmp_path / "f6.ogg"), str(Path(__file__).parent / "golden" / "reference_demo_40s.mp3")]
     pipe = Pipeline(model="GTINY", seed=5, batch_size=2)
     key = lambda segs: [(s.start, s.end, s.text, None if s.words is None else [(w.word, w.start, w.end) for w in s.words]) for s in segs]
     want = [key(pipe.transcribe(p, word_timestamps=True)) for p in paths]
-    assert [len(w) for w in want] == [1, 2, 1, 3, 1, 2]
+    assert [len(w) for w in want] == [1, 2, 1, 3, 1, 2, 1, 2]
     for _ in range(2):
         with ThreadPoolExecutor(max_workers=4) as ex:
             got = list(ex.map(lambda p: key(pipe.transcribe(p, word_timestamps=True)), paths))
