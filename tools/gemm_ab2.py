@@ -2,7 +2,8 @@
 """In-process A/B timing of GEMM kernel variants (libraries built by tools/build_gemm_variants.sh):
 rounds interleave the variants on the same operands; median and minimum per variant and shape, and a
 check that every variant's output equals the first one's bit for bit.
-Usage: gemm_ab2.py [--rows M] lib1.so lib2.so ...   (--rows 1536: the shapes of a single 30 s utterance)"""
+Usage: gemm_ab2.py [--rows M] [--packed] lib1.so lib2.so ...   (--rows 1536: the shapes of a single 30 s utterance;
+--packed: the weights in the packed layout the encoder keeps them in, through oasr_gemm_bf16_pw)"""
 import ctypes as C
 import sys
 from pathlib import Path
@@ -13,9 +14,14 @@ libs = []
 vp = C.c_void_p
 argv = sys.argv[1:]
 M = 48128
-if argv and argv[0] == "--rows":
-    M = int(argv[1])
-    argv = argv[2:]
+packed = False
+while argv and argv[0] in ("--rows", "--packed"):
+    if argv[0] == "--rows":
+        M = int(argv[1])
+        argv = argv[2:]
+    else:
+        packed = True
+        argv = argv[1:]
 extra = []
 while argv and argv[0] == "--case":          # --case m n k epilogue
     extra.append(("case", int(argv[1]), int(argv[2]), int(argv[3]), int(argv[4])))
@@ -23,6 +29,8 @@ while argv and argv[0] == "--case":          # --case m n k epilogue
 for path in argv:
     h = C.CDLL(path)
     h.oasr_gemm_bf16.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_int32, vp]
+    h.oasr_gemm_bf16_pw.argtypes = h.oasr_gemm_bf16.argtypes
+    h.oasr_gemm_pack_w_bf16.argtypes = [vp, C.c_int64, C.c_int64, vp, vp]
     libs.append((Path(path).stem.replace("abl_gemm_", ""), h))
 # the first case is repeated at the end: the first launches of a fresh process on a fresh machine can run slow
 cases = [("ffn_up swish", M, 4096, 1024, 1), ("ffn_down resid", M, 1024, 4096, 3),
@@ -41,6 +49,11 @@ for name, m, n, k, epi in cases:
     odt = torch.float32 if epi in (3, 4) else torch.bfloat16
     oshape = (m, n // 2 if epi == 2 else n)
     resid = torch.randn(oshape, generator=g).to(dev) if epi == 3 else None
+    if packed:
+        wp = torch.empty_like(w)
+        assert libs[0][1].oasr_gemm_pack_w_bf16(w.data_ptr(), n, k, wp.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        w = wp
     outs = []
     times = {tag: [] for tag, _ in libs}
     for rnd in range(7):
@@ -51,7 +64,7 @@ for name, m, n, k, epi in cases:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(10):
-                rc = h.oasr_gemm_bf16(*args)
+                rc = (h.oasr_gemm_bf16_pw if packed else h.oasr_gemm_bf16)(*args)
             e1.record()
             e1.synchronize()
             assert rc == 0
