@@ -217,13 +217,15 @@ static bool read_residual(BitReader& br, int64_t* out, int blocksize, int pred_o
 
 // s[i] += (sum_j coef[j] * s[i - 1 - j]) >> shift for i >= ORDER: the order is a compile-time constant for the
 // orders encoders use, so the inner sum is straight-line code.
+// (Sums and products wrap modulo 2^64 - unsigned arithmetic, reinterpreted: a valid stream stays far inside the range,
+// a damaged one may not, and its garbage must not be undefined behaviour.)
 template <int ORDER>
 static void lpc_restore_n(int64_t* s, int blocksize, const int64_t* coef, int shift) {
     for (int i = ORDER; i < blocksize; ++i) {
-        int64_t acc = 0;
+        uint64_t acc = 0;
 #pragma GCC unroll 32
-        for (int j = 0; j < ORDER; ++j) acc += coef[j] * s[i - 1 - j];
-        s[i] += acc >> shift;
+        for (int j = 0; j < ORDER; ++j) acc += (uint64_t)coef[j] * (uint64_t)s[i - 1 - j];
+        s[i] = (int64_t)((uint64_t)s[i] + (uint64_t)((int64_t)acc >> shift));
     }
 }
 static void lpc_restore(int64_t* s, int blocksize, int order, const int64_t* coef, int shift) {
@@ -235,9 +237,9 @@ static void lpc_restore(int64_t* s, int blocksize, int order, const int64_t* coe
         default: break;
     }
     for (int i = order; i < blocksize; ++i) {
-        int64_t acc = 0;
-        for (int j = 0; j < order; ++j) acc += coef[j] * s[i - 1 - j];
-        s[i] += acc >> shift;
+        uint64_t acc = 0;
+        for (int j = 0; j < order; ++j) acc += (uint64_t)coef[j] * (uint64_t)s[i - 1 - j];
+        s[i] = (int64_t)((uint64_t)s[i] + (uint64_t)((int64_t)acc >> shift));
     }
 }
 
@@ -259,15 +261,17 @@ static bool read_subframe(BitReader& br, int64_t* s, int blocksize, int bps) {
         for (int i = 0; i < order; ++i) s[i] = br.get_signed(bps);
         if (!read_residual(br, s + order, blocksize, order)) return false;
         for (int i = order; i < blocksize; ++i) {
-            int64_t pred = 0;
+            const uint64_t a = (uint64_t)s[i - 1], b = order > 1 ? (uint64_t)s[i - 2] : 0, c = order > 2 ? (uint64_t)s[i - 3] : 0,
+                           d = order > 3 ? (uint64_t)s[i - 4] : 0;
+            uint64_t pred = 0;   // modulo 2^64, as above
             switch (order) {
-                case 1: pred = s[i - 1]; break;
-                case 2: pred = 2 * s[i - 1] - s[i - 2]; break;
-                case 3: pred = 3 * s[i - 1] - 3 * s[i - 2] + s[i - 3]; break;
-                case 4: pred = 4 * s[i - 1] - 6 * s[i - 2] + 4 * s[i - 3] - s[i - 4]; break;
+                case 1: pred = a; break;
+                case 2: pred = 2 * a - b; break;
+                case 3: pred = 3 * a - 3 * b + c; break;
+                case 4: pred = 4 * a - 6 * b + 4 * c - d; break;
                 default: break;
             }
-            s[i] += pred;
+            s[i] = (int64_t)((uint64_t)s[i] + pred);
         }
     } else if (type >= 32) {
         const int order = (type & 31) + 1;
@@ -354,15 +358,16 @@ static size_t decode_frame(const uint8_t* d, size_t n, size_t pos, const StreamI
     if (br.bad || crc16(d + pos, body_len) != want16) return fail("frame CRC mismatch");
     int64_t* c0 = fs.ch[0].data();
     int64_t* c1 = fs.ch[1].data();
+    // (modulo 2^64 like the predictors: a damaged frame's values may be anything)
     if (ch_code == 8) {
-        for (int i = 0; i < blocksize; ++i) c1[i] = c0[i] - c1[i];
+        for (int i = 0; i < blocksize; ++i) c1[i] = (int64_t)((uint64_t)c0[i] - (uint64_t)c1[i]);
     } else if (ch_code == 9) {
-        for (int i = 0; i < blocksize; ++i) c0[i] = c1[i] + c0[i];
+        for (int i = 0; i < blocksize; ++i) c0[i] = (int64_t)((uint64_t)c1[i] + (uint64_t)c0[i]);
     } else if (ch_code == 10) {
         for (int i = 0; i < blocksize; ++i) {
-            const int64_t side = c1[i], mid = c0[i] * 2 + (side & 1);
-            c0[i] = (mid + side) >> 1;
-            c1[i] = (mid - side) >> 1;
+            const uint64_t side = (uint64_t)c1[i], mid = (uint64_t)c0[i] * 2 + (side & 1);
+            c0[i] = (int64_t)(mid + side) >> 1;
+            c1[i] = (int64_t)(mid - side) >> 1;
         }
     }
     return br.byte_pos();
@@ -382,7 +387,7 @@ static void emit(const FrameScratch& fs, int nch, int64_t take, const Sink& sk, 
         int16_t* dst = sk.o16 + at * nch;
         for (int c = 0; c < nch; ++c) {
             const int64_t* src = fs.ch[c].data() + skip;
-            for (int64_t i = 0; i < take; ++i) dst[i * nch + c] = (int16_t)(src[i] << sk.shift);
+            for (int64_t i = 0; i < take; ++i) dst[i * nch + c] = (int16_t)((uint64_t)src[i] << sk.shift);
         }
     } else {
         int32_t* dst = sk.o32 + at * nch;
