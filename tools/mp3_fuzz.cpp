@@ -1,6 +1,7 @@
 // Host-side fuzz harness for the MP3 decoder (csrc/mp3.cpp) under AddressSanitizer: a valid stream is damaged at
 // random (byte flips anywhere, bit flips aimed at side information, truncation, deleted and inserted runs, header
-// damage), copied into an exact-size heap block and decoded with 1, 2 or 5 threads into an exact-size output.  Any
+// damage), copied into an exact-size heap block and decoded with 1, 2 or 5 threads into an exact-size output, whole and
+// by random sample ranges of the opened stream.  Any
 // read or write outside a buffer aborts the run.
 // Build and run (host code only; no GPU is touched):
 //   hipcc -O1 -g -std=c++17 -Xarch_host -fsanitize=address -Iinclude -Iomnilingual-asr_amd/csrc -x hip \
@@ -20,6 +21,10 @@
 namespace oasr { void set_error(const char*, ...) {} }   // the library's error text is not needed here
 extern "C" int oasr_mp3_info(const uint8_t*, int64_t, int32_t*, int32_t*, int64_t*);
 extern "C" int oasr_mp3_decode(const uint8_t*, int64_t, float*, int64_t, int64_t*, int64_t*);
+struct oasr_mp3_stream;
+extern "C" int oasr_mp3_open(const uint8_t*, int64_t, oasr_mp3_stream**, int32_t*, int32_t*, int64_t*);
+extern "C" int oasr_mp3_decode_mono_range(const oasr_mp3_stream*, int64_t, int64_t, float*);
+extern "C" void oasr_mp3_close(oasr_mp3_stream*);
 int main(int argc, char** argv) {
     FILE* f = fopen(argv[1], "rb");
     fseek(f, 0, SEEK_END);
@@ -86,6 +91,26 @@ int main(int argc, char** argv) {
                 err++;
             }
             free(out);
+            // the opened-stream form: random sample ranges into exact-size outputs (each range warms up on the frames
+            // in front of it)
+            oasr_mp3_stream* st = nullptr;
+            int64_t t2 = 0;
+            if (oasr_mp3_open(p, b.size(), &st, &sr, &ch, &t2) == 0) {
+                for (int q = 0; q < 4 && t2 > 0; q++) {
+                    const int64_t first = (int64_t)(rng() % (uint64_t)t2);
+                    int64_t count = 1 + (int64_t)(rng() % (uint64_t)(t2 - first));
+                    if (rng() % 2) count = count < 3000 ? count : 1 + (int64_t)(rng() % 3000);
+                    float* o = (float*)malloc(sizeof(float) * (size_t)count);
+                    oasr_mp3_decode_mono_range(st, first, count, o);
+                    for (int64_t i = 0; i < count; i++)
+                        if (!(o[i] == o[i])) {
+                            printf("NaN in a range\n");
+                            return 1;
+                        }
+                    free(o);
+                }
+                oasr_mp3_close(st);
+            }
         } else {
             err++;
         }
