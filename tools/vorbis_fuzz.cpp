@@ -1,5 +1,6 @@
 // Host-side fuzz harness for the Ogg Vorbis decoder (csrc/vorbis.cpp) under AddressSanitizer.  A valid stream is
-// damaged at random and decoded with 1, 2 or 5 threads into an exact-size output; any read or write outside a buffer
+// damaged at random and decoded with 1, 2 or 5 threads into an exact-size output, whole and by random sample ranges of
+// the opened stream; any read or write outside a buffer
 // aborts the run.  Page checksums would stop almost every damaged byte at the container, so most kinds of damage are
 // applied to page bodies - the setup header's codebooks, floors, residues and mappings, and the audio packets - and
 // the checksum of every touched page is recomputed; the rest (truncation, deleted and inserted runs, header fields
@@ -23,6 +24,10 @@ namespace oasr { void set_error(const char*, ...) {} }   // the library's error 
 extern "C" int oasr_vorbis_info(const uint8_t*, int64_t, int32_t*, int32_t*, int64_t*);
 extern "C" int oasr_vorbis_decode(const uint8_t*, int64_t, float*, int64_t, int64_t*, int32_t);
 extern "C" int oasr_vorbis_decode_mono(const uint8_t*, int64_t, float*, int64_t, int64_t*, int32_t);
+struct oasr_vorbis_stream;
+extern "C" int oasr_vorbis_open(const uint8_t*, int64_t, oasr_vorbis_stream**, int32_t*, int32_t*, int64_t*);
+extern "C" int oasr_vorbis_decode_mono_range(const oasr_vorbis_stream*, int64_t, int64_t, float*);
+extern "C" void oasr_vorbis_close(oasr_vorbis_stream*);
 
 static uint32_t crc_tab[256];
 static uint32_t page_crc(const uint8_t* p, size_t n) {
@@ -128,6 +133,22 @@ int main(int argc, char** argv) {
             ++err;
         }
         free(out);
+        // the opened-stream form: random sample ranges into exact-size outputs
+        oasr_vorbis_stream* st = nullptr;
+        int64_t t2 = 0;
+        if (oasr_vorbis_open(heap, (int64_t)b.size(), &st, &rate, &ch, &t2) == 0) {
+            for (int q = 0; q < 4 && t2 > 0 && t2 < (1 << 24); q++) {
+                const int64_t first = (int64_t)(rng() % (uint64_t)t2);
+                int64_t count = 1 + (int64_t)(rng() % (uint64_t)(t2 - first));
+                if (rng() % 2) count = count < 3000 ? count : 1 + (int64_t)(rng() % 3000);
+                float* o = (float*)malloc(sizeof(float) * (size_t)count);
+                oasr_vorbis_decode_mono_range(st, first, count, o);
+                for (int64_t i = 0; i < count; ++i)
+                    if (!std::isfinite(o[i])) ++nonfinite;
+                free(o);
+            }
+            oasr_vorbis_close(st);
+        }
         free(heap);
     }
     printf("%d streams: %d decoded, %d refused, %ld non-finite samples\n", iters, ok, err, nonfinite);
