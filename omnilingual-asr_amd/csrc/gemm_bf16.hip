@@ -139,21 +139,28 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[MI][4],
                     const f32x2 lo = swish2((f32x2){v[0], v[1]}), hi = swish2((f32x2){v[2], v[3]});
                     v = (f32x4){lo[0], lo[1], hi[0], hi[1]};
                 }
-                *reinterpret_cast<uint2*>(slab + fr * kEpiPitch + j * 32 + fq * 8) =
+                // rows 8-15 keep the two 8-byte halves of every 16-byte chunk swapped: the 16 lanes of one LDS pass
+                // (rows 0-15 of one fq) would otherwise meet in pairs on the same banks (row pitch 36 dwords)
+                *reinterpret_cast<uint2*>(slab + fr * kEpiPitch + j * 32 + ((fq ^ (fr >> 3)) * 8)) =
                     make_uint2(cvt_pk_bf16(v[0], v[1]), cvt_pk_bf16(v[2], v[3]));
             }
             OASR_WAVE_LDS_SYNC();
             if (c_packed) {   // wave-uniform
-                const u32x4 p0 = *reinterpret_cast<const u32x4*>(slab + prow * kEpiPitch + pchunk * 16);
-                const u32x4 p1 = *reinterpret_cast<const u32x4*>(slab + prow * kEpiPitch + 64 + pchunk * 16);
+                u32x4 p0 = *reinterpret_cast<const u32x4*>(slab + prow * kEpiPitch + pchunk * 16);
+                u32x4 p1 = *reinterpret_cast<const u32x4*>(slab + prow * kEpiPitch + 64 + pchunk * 16);
                 OASR_WAVE_LDS_SYNC();
+                if (prow >= 8) {
+                    p0 = (u32x4){p0[2], p0[3], p0[0], p0[1]};
+                    p1 = (u32x4){p1[2], p1[3], p1[0], p1[1]};
+                }
                 char* dst = pbase + (int64_t)i * (N >> 5) * 1024;
                 store_nt16(dst, p0);
                 store_nt16(dst + 1024, p1);
             } else {
                 const u32x4 lo = *reinterpret_cast<const u32x4*>(slab + rrow * kEpiPitch + rchunk * 16);
-                const u32x4 hi = *reinterpret_cast<const u32x4*>(slab + (rrow + 8) * kEpiPitch + rchunk * 16);
+                const u32x4 hs = *reinterpret_cast<const u32x4*>(slab + (rrow + 8) * kEpiPitch + rchunk * 16);
                 OASR_WAVE_LDS_SYNC();
+                const u32x4 hi = {hs[2], hs[3], hs[0], hs[1]};
                 store_nt16(cbase + (int64_t)(i * 16) * N, lo);
                 store_nt16(cbase + (int64_t)(i * 16 + 8) * N, hi);
             }
