@@ -264,7 +264,7 @@ def test_two_ranks_share_the_gpu_through_the_long_audio_mode():
 def test_two_ranks_decode_only_their_shards_of_an_mp3():
     """Sharding a compressed file: two ranks (gloo, both on GPU 0) call the public long-audio entry on the reference's
     demo recording; each decodes about half of it (its chunks plus the rate converter's reach), and the merged
-    result on every rank equals the unsharded one (tools/sharded_mp3.py)."""
+    result on every rank equals the unsharded one (tools/sharded_ingest.py)."""
     import socket
     import subprocess
     import sys
@@ -275,7 +275,7 @@ def test_two_ranks_decode_only_their_shards_of_an_mp3():
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(root / "tools" / "sharded_mp3.py")]
+           "--master-port", str(port), str(root / "tools" / "sharded_ingest.py")]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=str(root))
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
     lines = [l for l in out.stdout.splitlines() if l.startswith("rank ")]
@@ -287,7 +287,7 @@ def test_two_ranks_read_only_their_shards_of_a_stereo_wav_a_flac_and_an_ogg():
     rank uploads and converts only the bytes of its shard, on the device), the reference's FLAC upload (a rank decodes
     only the frames that cover its shard) and a 22.05 kHz stereo Vorbis stream from the test writer (a rank decodes
     only the packets that cover its shard).  Each of the two ranks reads about half of the source samples and the
-    merged result equals the unsharded one, which loads the file whole (tools/sharded_mp3.py wav flac ogg)."""
+    merged result equals the unsharded one, which loads the file whole (tools/sharded_ingest.py wav flac ogg)."""
     import socket
     import subprocess
     import sys
@@ -298,7 +298,7 @@ def test_two_ranks_read_only_their_shards_of_a_stereo_wav_a_flac_and_an_ogg():
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(root / "tools" / "sharded_mp3.py"), "wav", "flac", "ogg"]
+           "--master-port", str(port), str(root / "tools" / "sharded_ingest.py"), "wav", "flac", "ogg"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=str(root))
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
     lines = [l for l in out.stdout.splitlines() if l.startswith("rank ")]

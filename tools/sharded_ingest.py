@@ -3,7 +3,7 @@
 Every rank calls the public long-audio entry on the same file; each reads and converts only the samples of its own
 shard of chunks (MP3 frames, FLAC frames, Vorbis packets, the bytes of a memory-mapped WAV), the records cross in the one all-gather,
 and every rank checks the merged result against a pipeline without a process group, which loads the file whole.
-Usage: python -m torch.distributed.run --nproc-per-node 2 tools/sharded_mp3.py [mp3|wav|flac|ogg ...]   (default: mp3)"""
+Usage: python -m torch.distributed.run --nproc-per-node 2 tools/sharded_ingest.py [mp3|wav|flac|ogg ...]   (default: mp3)"""
 import os, struct, sys, tempfile
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
