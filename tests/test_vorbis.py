@@ -6,8 +6,10 @@ kind, ref gemini_pipeline.py:106-118).  What pins the decoder instead:
     block sizes 256 / 2048, floor 1, coupled residue), found in this image's Python packages and kept as
     `tests/golden/mathjax_invalid_keypress.ogg`: every packet's residue decode ends inside the packet's last byte (an
     encoder writes no more than it needs; a wrong codeword table, floor or residue layout loses that within a few
-    symbols), the page checksums hold, and the decoded sound is a clean low tone - time-domain aliasing cancels to
-    1e-9 of the energy, where a decoder with the alias sign of the inverse MDCT flipped leaves 5e-5;
+    symbols), the page checksums hold, the decoded sound is a clean low tone - time-domain aliasing cancels to
+    1e-9 of the energy, where a decoder with the alias sign of the inverse MDCT flipped leaves 5e-5 - and every sample
+    equals the one `oracle/vorbis.py` computes, a second decoder written from the specification alone (codewords
+    matched bit by bit in a dictionary, the inverse MDCT as its cosine sum in float64);
 (2) the format's forward definitions: `tests/vorbis_tools.py` writes streams (codebooks of both lookup kinds, ordered
     and sparse length lists, floor-1 posts, residues 0 / 1 / 2 in cascaded passes, coupling, submaps, both block
     sizes with every window shape) and states the PCM each stands for, computed in float64 from the definitions."""
@@ -21,6 +23,7 @@ import pytest
 sys.path.insert(0, str(Path(__file__).parent))
 import vorbis_tools as vt  # noqa: E402
 from omnilingual_asr import _hip, audio  # noqa: E402
+from oracle import vorbis as OV  # noqa: E402
 
 
 def _decode(data: bytes, threads: int = 1, mono: bool = False):
@@ -65,6 +68,10 @@ def test_a_stream_from_a_real_encoder(golden_dir):
     assert power[hz > 1500].sum() / power.sum() < 1e-7
     mono, _ = audio.read_ogg_mono(path)
     np.testing.assert_array_equal(mono, x.mean(axis=1, dtype=np.float64).astype(np.float32))
+    # sample by sample against the restatement: float32 butterflies against a float64 cosine sum (measured 1.1e-7)
+    want, want_rate = OV.decode(data)
+    assert want_rate == rate and want.shape == x.shape
+    assert np.abs(x - want).max() < 1e-6
 
 
 def _signal(n, ch, seed):
@@ -115,6 +122,21 @@ def test_written_streams_decode_to_the_pcm_their_spectra_stand_for(name):
     assert np.abs(enc.expected).max() > 0.1
     mono, _ = _decode(enc.data, mono=True)
     np.testing.assert_array_equal(mono, out.mean(axis=1, dtype=np.float64).astype(np.float32))
+
+
+@pytest.mark.parametrize("name", ["mono residue 0, begin > 0", "mono table books with running sums, floor multiplier 4",
+                                  "stereo coupled residue 2", "stereo, a submap per channel (residues 0 and 1)",
+                                  "stereo residue 2, blocks 64 / 512, short first, end trimmed"])
+def test_the_restatement_reads_written_streams_too(name):
+    """The checker checked: `oracle/vorbis.py` against the forward definitions (streams whose start is trimmed by the
+    first page's granule position are left out: the restatement does not do that, and the real stream does not ask)."""
+    cfg = CONFIGS[name]
+    x = _signal(3000, cfg.channels, cfg.seed)
+    enc = vt.encode(x if cfg.channels > 1 else x[:, 0], cfg)
+    got, rate = OV.decode(enc.data)
+    assert rate == cfg.rate
+    assert got.shape == enc.expected.shape
+    assert np.abs(got - enc.expected).max() < 2e-6 * max(1.0, np.abs(enc.expected).max())
 
 
 def test_long_stream_any_thread_count_and_any_sample_range():
