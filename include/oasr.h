@@ -348,6 +348,12 @@ void oasr_vorbis_close(oasr_vorbis_stream* stream);
  * the packet).  An encoder writes no more than it needs, so with the right code books the figure stays below 8. */
 int oasr_vorbis_packet_tails(const uint8_t* data, int64_t size, int32_t* tails, int64_t capacity, int64_t* packets);
 
+/* FLAC in an Ogg container (another of the contents an `.ogg` upload can have, ref gemini_pipeline.py:114): writes the
+ * native FLAC stream the file wraps - signature, metadata blocks, frames - into `out` (never more than `size` bytes),
+ * for oasr_flac_info / oasr_flac_decode / oasr_flac_decode16 / oasr_flac_decode_range to read.  Page checksums and page
+ * sequence are verified as for Vorbis; a file that ends inside a page yields the frames of the whole pages. */
+int oasr_ogg_flac_unwrap(const uint8_t* data, int64_t size, uint8_t* out, int64_t capacity, int64_t* written);
+
 /* LayerNorm (optionally followed by Swish) straight to e4m3 rows + per-row scale: byte-identical to
  * oasr_layernorm(out_bf16=1) followed by oasr_quant_fp8_rows, without the intermediate bf16 matrix.
  * oasr_layernorm2_fp8 is the same for oasr_layernorm2 (x is overwritten with its first LayerNorm). */

@@ -132,8 +132,8 @@ struct Stream {
 static inline uint32_t le32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
 
 // `keep_bytes` false: only the packets' first byte and lengths are wanted (the sample count), so page bodies are neither
-// checked nor copied.
-static bool demux(const uint8_t* d, size_t n, Stream& s, std::string& err, bool keep_bytes = true) {
+// checked nor copied.  `flac`: the stream looked for is the FLAC mapping's (first packet 0x7f "FLAC") instead of Vorbis.
+static bool demux(const uint8_t* d, size_t n, Stream& s, std::string& err, bool keep_bytes = true, bool flac = false) {
     size_t pos = 0;
     bool have = false, in_packet = false, skipping = false, have_seq = false;
     uint32_t serial = 0, next_seq = 0;
@@ -182,14 +182,17 @@ static bool demux(const uint8_t* d, size_t n, Stream& s, std::string& err, bool 
         const uint8_t* bp = seg + nseg;
         const size_t page_end = pos + page_len;
         if (!have) {
-            if ((htype & 2) && body_len >= 7 && memcmp(bp, "\x01vorbis", 7) == 0) {
+            const bool is_vorbis = (htype & 2) && body_len >= 7 && memcmp(bp, "\x01vorbis", 7) == 0;
+            const bool is_flac = (htype & 2) && body_len >= 5 && memcmp(bp, "\x7f" "FLAC", 5) == 0;
+            if (flac ? is_flac : is_vorbis) {
                 serial = ser;
                 have = true;
             } else {
                 if ((htype & 2) && other.empty() && body_len >= 8) {
                     if (memcmp(bp, "OpusHead", 8) == 0) other = "Opus";
                     else if (memcmp(bp, "Speex   ", 8) == 0) other = "Speex";
-                    else if (memcmp(bp, "\x7f" "FLAC", 5) == 0) other = "FLAC-in-Ogg";
+                    else if (is_flac) other = "FLAC (to be unwrapped with oasr_ogg_flac_unwrap)";
+                    else if (is_vorbis) other = "Vorbis";
                     else other = "another codec";
                 }
                 pos = page_end;
@@ -226,7 +229,7 @@ static bool demux(const uint8_t* d, size_t n, Stream& s, std::string& err, bool 
                 in_packet = true;
             }
             size_t take = (size_t)l;
-            if (!keep_bytes && s.packets.size() >= 3) {   // an audio packet's mode is in its first byte
+            if (!keep_bytes && !flac && s.packets.size() >= 3) {   // an audio packet's mode is in its first byte
                 const size_t have = s.body.size() - cur_off;
                 take = have >= 2 ? 0 : std::min<size_t>(take, 2 - have);
             }
@@ -246,7 +249,8 @@ static bool demux(const uint8_t* d, size_t n, Stream& s, std::string& err, bool 
         if (htype & 4) break;
     }
     if (!have) {
-        err = other.empty() ? "ogg: no Vorbis stream found" : "ogg: the file holds " + other + ", not Vorbis";
+        const std::string want = flac ? "FLAC" : "Vorbis";
+        err = other.empty() ? "ogg: no " + want + " stream found" : "ogg: the file holds " + other + ", not " + want;
         return false;
     }
     if (in_packet) s.body.resize(cur_off);
@@ -1255,6 +1259,59 @@ int oasr_vorbis_decode_mono_range(const oasr_vorbis_stream* stream, int64_t firs
 }
 
 void oasr_vorbis_close(oasr_vorbis_stream* stream) { delete stream; }
+
+// FLAC in an Ogg container (the mapping of the FLAC format's Ogg annex): the first packet is 0x7f "FLAC", a mapping
+// version (major 1), the number of header packets that follow, then the native signature "fLaC" and the STREAMINFO
+// block; every further header packet is one metadata block; every audio packet is one FLAC frame.  The native stream is
+// therefore the packets' bytes in order, the first one from its ninth byte on - which is what this writes into `out`
+// (never more than `size` bytes), for oasr_flac_info / oasr_flac_decode* to read.
+int oasr_ogg_flac_unwrap(const uint8_t* data, int64_t size, uint8_t* out, int64_t capacity, int64_t* written) {
+    OASR_REQUIRE(data && size > 0 && out && written, "ogg_flac_unwrap: null pointer");
+    vorbis::Stream st;
+    std::string err;
+    if (!vorbis::demux(data, (size_t)size, st, err, true, true)) {
+        set_error("%s", err.c_str());
+        return OASR_EINVAL;
+    }
+    OASR_REQUIRE(!st.packets.empty() && st.packets[0].len >= 13 + 4 + 34, "ogg_flac_unwrap: the first packet is too short");
+    const uint8_t* p0 = st.body.data() + st.packets[0].off;
+    OASR_REQUIRE(p0[5] == 1, "ogg_flac_unwrap: mapping version %d.%d is not known", (int)p0[5], (int)p0[6]);
+    OASR_REQUIRE(memcmp(p0 + 9, "fLaC", 4) == 0 && (p0[13] & 0x7f) == 0, "ogg_flac_unwrap: no STREAMINFO in the first packet");
+    int64_t need = -9;
+    for (const vorbis::Packet& pk : st.packets) need += pk.len;
+    OASR_REQUIRE(need <= capacity, "ogg_flac_unwrap: %lld bytes, room for %lld", (long long)need, (long long)capacity);
+    // metadata blocks run until one carries the last-block flag; a packet after that which does not start with the
+    // frame synchronisation code is not part of the stream
+    int64_t at = 0;
+    bool in_headers = true;
+    for (size_t i = 0; i < st.packets.size(); ++i) {
+        const uint8_t* p = st.body.data() + st.packets[i].off;
+        size_t len = st.packets[i].len;
+        if (i == 0) {
+            p += 9;
+            len -= 9;
+            in_headers = (p[4] & 0x80) == 0;
+        } else if (in_headers) {
+            if (len < 4) {
+                set_error("ogg_flac_unwrap: a header packet of %zu bytes", len);
+                return OASR_EINVAL;
+            }
+            const size_t body = ((size_t)p[1] << 16) | ((size_t)p[2] << 8) | p[3];
+            if (body + 4 != len) {
+                set_error("ogg_flac_unwrap: a metadata block of %zu bytes in a packet of %zu", body + 4, len);
+                return OASR_EINVAL;
+            }
+            in_headers = (p[0] & 0x80) == 0;
+        } else if (len < 2 || p[0] != 0xff || (p[1] & 0xfc) != 0xf8) {
+            set_error("ogg_flac_unwrap: audio packet %zu does not start with a frame header", i);
+            return OASR_EINVAL;
+        }
+        memcpy(out + at, p, len);
+        at += (int64_t)len;
+    }
+    *written = at;
+    return OASR_OK;
+}
 
 // Diagnostic for tests: for every audio packet, the number of bits left unread when its residue decode finished
 // (-1: the decode ran into the end of the packet).  An encoder writes no more than it needs, so on an undamaged

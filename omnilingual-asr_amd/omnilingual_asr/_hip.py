@@ -119,6 +119,7 @@ _SIGNATURES = {
     "oasr_vorbis_decode_mono_range": (c_i32, [c_vp, c_i64, c_i64, c_vp]),
     "oasr_vorbis_close": (None, [c_vp]),
     "oasr_vorbis_packet_tails": (c_i32, [c_vp, c_i64, c_vp, c_i64, C.POINTER(c_i64)]),
+    "oasr_ogg_flac_unwrap": (c_i32, [c_vp, c_i64, c_vp, c_i64, C.POINTER(c_i64)]),
     "oasr_gather_chunks": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_i64, c_vp, c_vp]),
     "oasr_pcm_to_mono_f32": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "oasr_resample_length": (c_i64, [c_i64, c_i32, c_i32]),

@@ -71,7 +71,7 @@ def read_wav(path) -> tuple[np.ndarray, int]:
     data = path.read_bytes()
     if data[:4] not in _RIFF_MAGICS:
         raise UnsupportedAudioError(
-            f"cannot decode '{path.suffix}' audio: WAV, AIFF, FLAC, MP3 and Ogg Vorbis input is supported")
+            f"cannot decode '{path.suffix}' audio: WAV, AIFF, FLAC (also in Ogg), MP3 and Ogg Vorbis input is supported")
     fmt = payload = None
     for cid, body in _riff_chunks(data):
         if cid == b"fmt ":
@@ -236,8 +236,8 @@ def wav_duration(path) -> float:
 
 def audio_duration(path) -> float:
     """Duration in seconds without decoding, for every container `read_audio` decodes (WAV data chunk, AIFF
-    COMM chunk, FLAC STREAMINFO; MP3: its frame headers are counted; Ogg Vorbis: its pages are walked for the block
-    sizes and granule positions); raises on anything unreadable."""
+    COMM chunk, FLAC STREAMINFO - native or in an Ogg container; MP3: its frame headers are counted; Ogg Vorbis: its
+    pages are walked for the block sizes and granule positions); raises on anything unreadable."""
     with open(path, "rb") as f:
         head = f.read(1 << 16)
     if head[:4] in _RIFF_MAGICS and not _looks_like_mp3(head, path):
@@ -258,6 +258,13 @@ def audio_duration(path) -> float:
         rate, total = x >> 44, x & ((1 << 36) - 1)
         if rate > 0 and total > 0:
             return total / float(rate)
+    if head[:4] == b"OggS" and _ogg_holds_flac(head):
+        at = 27 + head[26] + 9                  # the native signature inside the first packet
+        x = int.from_bytes(head[at + 18: at + 26], "big")
+        rate, total = x >> 44, x & ((1 << 36) - 1)
+        if rate > 0 and total > 0:
+            return total / float(rate)
+        raise UnsupportedAudioError("no duration in the header")
     if head[:4] == b"OggS":
         rate, _, total = vorbis_info(path)
         return total / float(rate)
@@ -404,13 +411,46 @@ def read_aiff(path) -> tuple[np.ndarray, int]:
     return x[: n * channels].reshape(n, channels), rate
 
 
-def read_flac(path) -> tuple[np.ndarray, int]:
-    """Decode a FLAC file with the native decoder -> (float32 [frames, channels] in [-1, 1), rate)."""
+def _ogg_holds_flac(head: bytes) -> bool:
+    """The first page of an Ogg file opens a FLAC stream (first packet 0x7f "FLAC": the FLAC format's Ogg mapping)."""
+    return head[:4] == b"OggS" and len(head) > 27 and head[27 + head[26]: 32 + head[26]] == b"\x7fFLAC"
+
+
+def is_flac(path) -> bool:
+    """A native FLAC stream (behind an ID3 tag only under its own suffix: the tag is an MP3's too) or FLAC in Ogg."""
+    with open(path, "rb") as f:
+        head = f.read(27 + 255 + 5)
+    return head[:4] == b"fLaC" or (head[:3] == b"ID3" and Path(path).suffix.lower() == ".flac") or _ogg_holds_flac(head)
+
+
+def _flac_bytes(path, mapped: bool = False) -> np.ndarray:
+    """The file's native FLAC stream as uint8: the file itself (memory-mapped when asked), or what an Ogg container
+    wraps (`oasr_ogg_flac_unwrap`: the packets' bytes in order)."""
+    with open(path, "rb") as f:
+        head = f.read(27 + 255 + 5)
+    if not _ogg_holds_flac(head):
+        return np.memmap(path, dtype=np.uint8, mode="r") if mapped else np.fromfile(path, dtype=np.uint8)
     import ctypes as C
 
     from . import _hip
-    data = Path(path).read_bytes()
-    buf = np.frombuffer(data, dtype=np.uint8)
+    wrapped = np.fromfile(path, dtype=np.uint8)
+    out = np.empty(wrapped.size, dtype=np.uint8)
+    written = C.c_int64()
+    try:
+        _hip.check(_hip.lib().oasr_ogg_flac_unwrap(wrapped.ctypes.data, wrapped.size, out.ctypes.data, out.size,
+                                                   C.byref(written)), "oasr_ogg_flac_unwrap")
+    except _hip.OasrError as e:
+        raise UnsupportedAudioError(str(e)) from e
+    return out[: written.value]
+
+
+def read_flac(path) -> tuple[np.ndarray, int]:
+    """Decode a FLAC file (native or in an Ogg container) with the native decoder -> (float32 [frames, channels] in
+    [-1, 1), rate)."""
+    import ctypes as C
+
+    from . import _hip
+    buf = _flac_bytes(path)
     rate, channels, bits, total = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
     L = _hip.lib()
     _hip.check(L.oasr_flac_info(buf.ctypes.data, buf.size, C.byref(rate), C.byref(channels), C.byref(bits),
@@ -432,12 +472,9 @@ def read_flac_pcm(path):
     import ctypes as C
 
     from . import _hip
-    with open(path, "rb") as f:
-        head = f.read(4)
-    if head != b"fLaC" and head[:3] != b"ID3":
+    if not is_flac(path):
         return None
-    data = Path(path).read_bytes()
-    buf = np.frombuffer(data, dtype=np.uint8)
+    buf = _flac_bytes(path)
     rate, channels, bits, total = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
     L = _hip.lib()
     _hip.check(L.oasr_flac_info(buf.ctypes.data, buf.size, C.byref(rate), C.byref(channels), C.byref(bits),
@@ -455,15 +492,12 @@ def read_flac_pcm(path):
 
 def read_flac_pcm16(path):
     """(int16 interleaved, channels, sample_rate) of a FLAC file with at most 16 bits per sample, else None."""
-    with open(path, "rb") as f:
-        head = f.read(4)
-    if head != b"fLaC" and head[:3] != b"ID3":
+    if not is_flac(path):
         return None
     import ctypes as C
 
     from . import _hip
-    data = Path(path).read_bytes()
-    buf = np.frombuffer(data, dtype=np.uint8)
+    buf = _flac_bytes(path)
     rate, channels, bits, total = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
     _hip.check(_hip.lib().oasr_flac_info(buf.ctypes.data, buf.size, C.byref(rate), C.byref(channels), C.byref(bits),
                                          C.byref(total), None), "oasr_flac_info")
@@ -485,7 +519,7 @@ class FlacStream:
 
         from . import _hip
         self._lib = _hip.lib()
-        self._buf = np.memmap(path, dtype=np.uint8, mode="r")
+        self._buf = _flac_bytes(path, mapped=True)       # (FLAC in Ogg: the unwrapped stream, held in memory)
         rate, channels, bits, total = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
         try:
             _hip.check(self._lib.oasr_flac_info(self._buf.ctypes.data, self._buf.size, C.byref(rate), C.byref(channels),
@@ -680,8 +714,10 @@ def is_mp3(path) -> bool:
 
 
 def is_ogg(path) -> bool:
+    """An Ogg file for the Vorbis decoder (FLAC in Ogg goes with FLAC: `is_flac`)."""
     with open(path, "rb") as f:
-        return f.read(4) == b"OggS"
+        head = f.read(27 + 255 + 5)
+    return head[:4] == b"OggS" and not _ogg_holds_flac(head)
 
 
 def _vorbis_call(path, mono: bool):
@@ -713,7 +749,7 @@ def vorbis_info(path) -> tuple[int, int, int]:
 
 def read_ogg(path) -> tuple[np.ndarray, int]:
     """Decode the first Vorbis stream of an Ogg file with the native decoder -> (float32 [frames, channels], rate);
-    not clipped.  Opus, Speex and FLAC in an Ogg container are refused by name."""
+    not clipped.  Opus and Speex in an Ogg container are refused by name (FLAC in Ogg: `read_flac`)."""
     out, rate, _, _ = _vorbis_call(path, False)
     return out, rate
 
@@ -773,19 +809,19 @@ class VorbisStream:
 def read_audio(path) -> tuple[np.ndarray, int]:
     """Decode by content: (float32 [frames, channels], sample_rate)."""
     with open(path, "rb") as f:
-        head = f.read(12)
+        head = f.read(27 + 255 + 5)
     if head[:4] in _RIFF_MAGICS:
         return read_mp3(path) if _looks_like_mp3(head, path) else read_wav(path)
     if head[:4] == b"FORM":
         return read_aiff(path)
-    if head[:4] == b"fLaC" or head[:3] == b"ID3" and Path(path).suffix.lower() == ".flac":
+    if head[:4] == b"fLaC" or head[:3] == b"ID3" and Path(path).suffix.lower() == ".flac" or _ogg_holds_flac(head):
         return read_flac(path)
     if head[:4] == b"OggS":
         return read_ogg(path)
     if _looks_like_mp3(head, path) or _is_mp3_behind_junk(head, path):
         return read_mp3(path)
     raise UnsupportedAudioError(
-        f"cannot decode '{Path(path).suffix}' audio: WAV, AIFF, FLAC, MP3 and Ogg Vorbis input is supported")
+        f"cannot decode '{Path(path).suffix}' audio: WAV, AIFF, FLAC (also in Ogg), MP3 and Ogg Vorbis input is supported")
 
 
 def load_audio_16k(path, resampler=None, keep_int16: bool = False) -> np.ndarray:

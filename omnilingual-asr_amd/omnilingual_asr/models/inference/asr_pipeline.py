@@ -475,7 +475,7 @@ class GeminiASRPipeline:
         `load_audio_16k`); the rate conversion runs on the device when the engine offers it."""
         if hasattr(self.engine, "pcm_to_16k"):
             mapped = _audio.map_wav_pcm(audio_path)        # integer PCM WAV: the device takes the file's samples as they are
-            if mapped is None and Path(audio_path).suffix.lower() == ".flac":
+            if mapped is None and _audio.is_flac(audio_path):
                 mapped = _audio.read_flac_pcm(audio_path)  # FLAC: decoded to the same form by the native decoder
             if mapped is not None:
                 samples, channels, rate, sample_bytes, bits = mapped
@@ -540,9 +540,7 @@ class GeminiASRPipeline:
             if channels == 1 and rate == SAMPLE_RATE and sample_bytes == 2 and bits == 16:
                 return None
             return _PcmSpans(samples, channels, rate, sample_bytes, bits)
-        with open(audio_path, "rb") as f:
-            head = f.read(4)
-        if head == b"fLaC":
+        if _audio.is_flac(audio_path):
             try:
                 src = _FlacSpans(audio_path)
             except Exception:

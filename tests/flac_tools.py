@@ -112,3 +112,26 @@ def repeat_stream(data: bytes, repeats: int, decoded: np.ndarray):
     stream = b"fLaC" + bytes([0x80]) + len(new_info).to_bytes(3, "big") + new_info + b"".join(out)
     want = np.concatenate([decoded[:n_full]] * repeats + [decoded[n_full:]], axis=0)
     return stream, want
+
+
+def wrap_in_ogg(data: bytes, per_page: int = 6, comment: bytes = b"", unknown_total: bool = False) -> bytes:
+    """The native stream `data` in an Ogg container, as the FLAC format's Ogg mapping lays it out: first packet
+    0x7f "FLAC" 1.0, the count of header packets that follow, "fLaC" and the STREAMINFO block, on a page of its own;
+    a VORBIS_COMMENT block as the one further header packet; then one packet per frame, `per_page` frames a page,
+    granule position = samples completed.  `unknown_total`: STREAMINFO states no sample count (a streamed encode)."""
+    import vorbis_tools as vt
+    info, frames = split_stream(data)
+    if unknown_total:
+        x = int.from_bytes(info[10:18], "big") & ~((1 << 36) - 1)
+        info = info[:10] + x.to_bytes(8, "big") + info[18:]
+    block = int.from_bytes(info[2:4], "big")
+    total = int.from_bytes(info[10:18], "big") & ((1 << 36) - 1)
+    vendor = b"flac_tools"
+    body = struct.pack("<I", len(vendor)) + vendor + struct.pack("<I", 1 if comment else 0)
+    if comment:
+        body += struct.pack("<I", len(comment)) + comment
+    first = b"\x7fFLAC\x01\x00" + struct.pack(">H", 1) + b"fLaC" + bytes([0x00]) + len(info).to_bytes(3, "big") + info
+    packets = [first, bytes([0x84]) + len(body).to_bytes(3, "big") + body] + frames
+    granules = [0, 0] + [min((i + 1) * block, total) if total else (i + 1) * block for i in range(len(frames))]
+    pages = [1, 1] + [per_page] * (len(frames) // per_page + 1)
+    return vt.ogg_pages(packets, granules, serial=0x464C, per_page=pages)

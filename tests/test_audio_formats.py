@@ -339,3 +339,73 @@ def test_aiff_that_states_no_sample_width_is_refused(tmp_path):
         p.write_bytes(b"FORM" + struct.pack(">I", len(body)) + body)
         with pytest.raises(audio.UnsupportedAudioError):
             audio.read_audio(p)
+
+def test_flac_in_an_ogg_container_is_unwrapped_and_read_like_the_native_stream(golden_dir, tmp_path, tiny_engine):
+    """The reference's FLAC upload wrapped page by page as the FLAC format's Ogg mapping lays it out
+    (tests/flac_tools.py: `wrap_in_ogg`; parity unpinned - no encoder for that mapping exists here): the unwrapped
+    bytes are the native stream's signature, metadata and frames; samples, duration, sample ranges and the transcript
+    equal the native file's; a stream that states no length is counted by decoding; a damaged page, a frame that does
+    not start with the synchronisation code and a truncated file behave like their Vorbis counterparts."""
+    import flac_tools as ft
+    from omnilingual_asr import Pipeline
+
+    src = golden_dir / "reference_upload.flac"
+    native = src.read_bytes()
+    x, rate = audio.read_flac(src)
+    wrapped = ft.wrap_in_ogg(native, comment=b"TITLE=upload")
+    p = tmp_path / "upload.ogg"
+    p.write_bytes(wrapped)
+    assert audio.is_flac(p) and not audio.is_ogg(p) and not audio.is_mp3(p)
+    # the unwrapped stream: the native file's STREAMINFO and frames around the one comment block the wrapper wrote
+    plain = audio._flac_bytes(p).tobytes()
+    info, frames = ft.split_stream(native)
+    info2, frames2 = ft.split_stream(plain)
+    assert plain[:4] == b"fLaC" and info2 == info and frames2 == frames and b"TITLE=upload" in plain[:200]
+    y, r = audio.read_audio(p)
+    assert r == rate and np.array_equal(y, x)
+    assert audio.audio_duration(p) == audio.audio_duration(src)
+    s16, ch, r16 = audio.read_flac_pcm16(p)
+    assert (ch, r16) == (1, rate) and np.array_equal(s16.astype(np.float32) / 32768.0, x[:, 0])
+    np.testing.assert_array_equal(audio.load_audio_16k(p), audio.load_audio_16k(src))
+    with audio.FlacStream(p) as fs:
+        assert fs.seekable and fs.samples == x.shape[0]
+        got = fs.read_pcm(100000, 5000)
+        assert np.array_equal(got.astype(np.float32) / 32768.0, x[100000:105000, 0])
+    a = Pipeline(engine=tiny_engine).transcribe(str(src))
+    b = Pipeline(engine=tiny_engine).transcribe(str(p))
+    assert [(s.start, s.end, s.text) for s in a] == [(s.start, s.end, s.text) for s in b] and a[0].text
+    # no stated length
+    p.write_bytes(ft.wrap_in_ogg(native, per_page=3, unknown_total=True))
+    y, _ = audio.read_audio(p)
+    assert np.array_equal(y, x)
+    with pytest.raises(audio.UnsupportedAudioError, match="no duration"):
+        audio.audio_duration(p)
+    # damage inside a page: the checksum says so
+    bad = bytearray(wrapped)
+    bad[len(bad) // 2] ^= 1
+    p.write_bytes(bytes(bad))
+    with pytest.raises(audio.UnsupportedAudioError, match="checksum"):
+        audio.read_audio(p)
+    # a page whose packet is not a frame (checksum made right again)
+    import vorbis_tools as vt
+    at = wrapped.index(b"OggS", wrapped.index(b"OggS", 100) + 4)      # the first audio page
+    nseg = wrapped[at + 26]
+    body = at + 27 + nseg
+    bad = bytearray(wrapped)
+    bad[body] = 0x00
+    size = 27 + nseg + sum(wrapped[at + 27: at + 27 + nseg])
+    page = bytes(bad[at: at + 22]) + bytes(4) + bytes(bad[at + 26: at + size])
+    bad[at + 22: at + 26] = struct.pack("<I", vt.ogg_crc(page))
+    p.write_bytes(bytes(bad))
+    with pytest.raises(audio.UnsupportedAudioError, match="does not start with a frame header"):
+        audio.read_audio(p)
+    # a file cut inside a page: the frames of the whole pages, as a native file cut short gives its whole frames
+    for data in (wrapped, ft.wrap_in_ogg(native, unknown_total=True)):
+        p.write_bytes(data[: len(data) * 2 // 3])
+        y, _ = audio.read_audio(p)
+        assert 0.5 * x.shape[0] < y.shape[0] < 0.75 * x.shape[0] and np.array_equal(y, x[: y.shape[0]])
+    # a Vorbis reader asked for this file names what it holds
+    d = np.frombuffer(wrapped, dtype=np.uint8)
+    ra, ca, ta = C.c_int32(), C.c_int32(), C.c_int64()
+    with pytest.raises(_hip.OasrError, match="holds FLAC"):
+        _hip.check(_hip.lib().oasr_vorbis_info(d.ctypes.data, d.size, C.byref(ra), C.byref(ca), C.byref(ta)))

@@ -197,12 +197,14 @@ def _worker_spans(rank, world, port, files, out_dir):
 def test_two_ranks_read_only_their_shards_of_wav_flac_and_ogg_files(tmp_path, golden_dir):
     """Under a process group a rank reads and converts only the source samples of its own shard of chunks: a 48 kHz
     stereo 16-bit WAV, a 44.1 kHz mono 24-bit WAV (ratio 160 / 441, so the converter's reach matters) and the
-    reference's FLAC upload (frames decoded by range) and an Ogg Vorbis stream (packets decoded by range).  Each rank
+    reference's FLAC upload (frames decoded by range), an Ogg Vorbis stream (packets decoded by range) and the FLAC
+    upload wrapped in Ogg pages (unwrapped by every rank, frames decoded by range).  Each rank
     touches about half of every file (its chunks plus
     the converter's reach), and the merged result on both ranks equals the single-process result, which loads the
     file whole."""
     from omnilingual_asr import audio
-    files = [tmp_path / "stereo48.wav", tmp_path / "mono441.wav", golden_dir / "reference_upload.flac", tmp_path / "stereo22.ogg"]
+    files = [tmp_path / "stereo48.wav", tmp_path / "mono441.wav", golden_dir / "reference_upload.flac", tmp_path / "stereo22.ogg",
+             tmp_path / "flac_inside.ogg"]
     _write_pcm_wav(files[0], 7.4, 48000, 2, 2, seed=1)
     _write_pcm_wav(files[1], 6.3, 44100, 1, 3, seed=2)
     # an Ogg Vorbis stream from the test writer (coupled stereo, both block sizes), its packets repeated to ~ 9 s:
@@ -212,10 +214,13 @@ def test_two_ranks_read_only_their_shards_of_wav_flac_and_ogg_files(tmp_path, go
     enc = vt.encode(0.1 * rng.standard_normal((22050 * 3, 2)), vt.Config(channels=2, rate=22050, pattern="LLSL", seed=6,
                                                                       residue_type=2, coupled=True, bs0=128, bs1=1024))
     files[3].write_bytes(vt.repeat_stream(enc, 3))
-    totals = [int(7.4 * 48000), int(6.3 * 44100), 312060, audio.vorbis_info(files[3])[2]]
+    import flac_tools as ft
+    files[4].write_bytes(ft.wrap_in_ogg(files[2].read_bytes()))
+    totals = [int(7.4 * 48000), int(6.3 * 44100), 312060, audio.vorbis_info(files[3])[2], 312060]
     single, _ = _make_pipeline(None)
     want = {str(f): [(s.start, s.end, s.speaker, s.text) for s in single.transcribe(str(f))] for f in files}
-    assert [len(want[str(f)]) for f in files] == [8, 7, 20, -(-totals[3] // 22050)]
+    assert [len(want[str(f)]) for f in files] == [8, 7, 20, -(-totals[3] // 22050), 20]
+    assert want[str(files[4])] == want[str(files[2])]
     port = _free_port()
     mp.spawn(_worker_spans, args=(2, port, [str(f) for f in files], str(tmp_path)), nprocs=2, join=True)
     r = [torch.load(tmp_path / f"spans{k}.pt") for k in range(2)]
@@ -226,7 +231,7 @@ def test_two_ranks_read_only_their_shards_of_wav_flac_and_ogg_files(tmp_path, go
         # rank 0 holds the first ceil(n / 2) one-second chunks, rank 1 the rest (the last one short); each reads
         # those source samples and the converter's reach (at most 1 500 samples a side), nothing more
         n_chunks = len(want[str(f)])
-        rate = {0: 48000, 1: 44100, 2: 16000, 3: 22050}[files.index(f)]
+        rate = {0: 48000, 1: 44100, 2: 16000, 3: 22050, 4: 16000}[files.index(f)]
         own0 = (n_chunks + 1) // 2 * rate
         reach = 1500 if rate == 22050 else 1000      # (320 / 441: the halo is a whole number of 441-sample periods)
         assert own0 <= a["read"] <= own0 + reach, (f, a["read"], own0)

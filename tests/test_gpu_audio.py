@@ -1,6 +1,8 @@
 """GPU test of the device polyphase resampler through the C ABI, against the host implementation
 (which tests/test_audio.py pins to scipy.signal.resample_poly)."""
 
+from pathlib import Path
+
 import numpy as np
 import pytest
 import torch
@@ -124,6 +126,23 @@ def test_flac_upload_through_the_device_decode(golden_dir):
     bounds = np.array([[0, kept.shape[0]]])
     a, b = pipe._encode_chunks(kept, bounds), pipe._encode_chunks(flt, bounds)
     assert a[0].n_frames == b[0].n_frames and np.array_equal(a[0].tokens, b[0].tokens)
+
+
+def test_flac_in_ogg_through_the_device_path_equals_the_native_file(golden_dir, tmp_path):
+    """The same upload wrapped in Ogg pages: the device path takes the unwrapped stream's samples as the native file's."""
+    import sys
+    sys.path.insert(0, str(Path(__file__).parent))
+    import flac_tools as ft
+    from omnilingual_asr import Pipeline
+
+    src = golden_dir / "reference_upload.flac"
+    p = tmp_path / "upload.ogg"
+    p.write_bytes(ft.wrap_in_ogg(src.read_bytes()))
+    pipe = Pipeline(model="GTINY")
+    kept = pipe.gemini._load_audio(p)
+    assert kept.dtype == np.int16 and np.array_equal(kept, pipe.gemini._load_audio(src))
+    a, b = pipe.transcribe(str(src)), pipe.transcribe(str(p))
+    assert [(s.start, s.end, s.text) for s in a] == [(s.start, s.end, s.text) for s in b] and a[0].text
 
 
 def test_mp3_demo_through_the_device_path(golden_dir):

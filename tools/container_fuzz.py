@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fuzz of the container readers (host code only): small valid files of every kind the package decodes - WAV (16- and
-24-bit PCM, mu-law, IMA ADPCM), AIFF, FLAC, MP3, Ogg Vorbis - are damaged at random (header bytes overwritten, truncation, bit
+24-bit PCM, mu-law, IMA ADPCM), AIFF, FLAC (native and in Ogg), MP3, Ogg Vorbis - are damaged at random (header bytes overwritten, truncation, bit
 flips anywhere, size fields replaced by extreme values) and loaded through `audio.load_audio_16k` under a 12 GB
 address-space limit.  Every file must either decode or be refused with UnsupportedAudioError / OasrError; any other
 exception, a MemoryError (a header obeyed instead of checked) or a load of more than 1.5 s is reported.
@@ -9,6 +9,7 @@ import collections, math, os, resource, struct, sys, tempfile, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "omnilingual-asr_amd"))
+sys.path.insert(0, str(ROOT / "tests"))
 resource.setrlimit(resource.RLIMIT_AS, (12 << 30, 12 << 30))
 import numpy as np
 from omnilingual_asr import _hip, audio
@@ -44,6 +45,8 @@ seeds = {
     "x.mp3": (gold / "reference_demo_40s.mp3").read_bytes()[:40000],
     "x.ogg": (gold / "mathjax_invalid_keypress.ogg").read_bytes(),
 }
+import flac_tools  # noqa: E402  (tests/: the Ogg wrapper for FLAC streams)
+seeds["flac_in.ogg"] = flac_tools.wrap_in_ogg(seeds["x.flac"], comment=b"A=B")
 for name, blob in seeds.items():          # every seed decodes as it is (and the library is loaded before timing starts)
     p = os.path.join(tempfile.gettempdir(), "oasr_fz_" + name)
     open(p, "wb").write(blob)

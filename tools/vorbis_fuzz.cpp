@@ -12,6 +12,7 @@
 //   /opt/rocm/lib/llvm/bin/clang++ -O1 -g -fsanitize=address,undefined tools/vorbis_fuzz.cpp /tmp/vorbis_asan.o \
 //         -o /tmp/vorbis_fuzz -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib -lpthread
 //   ASAN_OPTIONS=detect_leaks=0 /tmp/vorbis_fuzz tests/golden/mathjax_invalid_keypress.ogg 2000
+// (a FLAC-in-Ogg seed - tests/flac_tools.py: wrap_in_ogg - exercises oasr_ogg_flac_unwrap the same way)
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -28,6 +29,7 @@ struct oasr_vorbis_stream;
 extern "C" int oasr_vorbis_open(const uint8_t*, int64_t, oasr_vorbis_stream**, int32_t*, int32_t*, int64_t*);
 extern "C" int oasr_vorbis_decode_mono_range(const oasr_vorbis_stream*, int64_t, int64_t, float*);
 extern "C" void oasr_vorbis_close(oasr_vorbis_stream*);
+extern "C" int oasr_ogg_flac_unwrap(const uint8_t*, int64_t, uint8_t*, int64_t, int64_t*);
 
 static uint32_t crc_tab[256];
 static uint32_t page_crc(const uint8_t* p, size_t n) {
@@ -69,7 +71,7 @@ int main(int argc, char** argv) {
     if (fread(d.data(), 1, n, f) != (size_t)n) return 2;
     const int iters = atoi(argv[2]);
     std::mt19937_64 rng(argc > 3 ? atol(argv[3]) : 5);
-    int ok = 0, err = 0;
+    int ok = 0, err = 0, unwrapped = 0;
     long nonfinite = 0;
     for (int it = 0; it < iters; it++) {
         std::vector<uint8_t> b(d);
@@ -115,6 +117,15 @@ int main(int argc, char** argv) {
         memcpy(heap, b.data(), b.size());
         int32_t rate = 0, ch = 0;
         int64_t total = 0, written = 0;
+        {   // the FLAC mapping's unwrap on the same bytes (a seed file of that kind gets past the first packet)
+            uint8_t* plain = (uint8_t*)malloc(b.size());
+            int64_t w = 0;
+            if (oasr_ogg_flac_unwrap(heap, (int64_t)b.size(), plain, (int64_t)b.size(), &w) == 0) {
+                ++unwrapped;
+                if (w < 4 + 4 + 34 || w > (int64_t)b.size() || memcmp(plain, "fLaC", 4) != 0) abort();
+            }
+            free(plain);
+        }
         if (oasr_vorbis_info(heap, (int64_t)b.size(), &rate, &ch, &total) != 0 || total > (1 << 24)) {
             ++err;
             free(heap);
@@ -151,6 +162,7 @@ int main(int argc, char** argv) {
         }
         free(heap);
     }
-    printf("%d streams: %d decoded, %d refused, %ld non-finite samples\n", iters, ok, err, nonfinite);
+    printf("%d streams: %d decoded, %d refused, %ld non-finite samples; %d unwrapped as FLAC in Ogg\n", iters, ok, err,
+           nonfinite, unwrapped);
     return 0;
 }
