@@ -322,7 +322,9 @@ void oasr_mp3_close(oasr_mp3_stream* stream);
  * MIME table, workflows/wav2elan_web/app.py:76-77; the reference forwards the bytes to its remote model).  The first
  * Vorbis stream of an Ogg file (page checksums verified; other multiplexed streams stepped over; Opus, Speex or FLAC in
  * Ogg named in the error): Vorbis I with floor 1, residues 0 / 1 / 2, channel coupling, both block sizes; floor 0
- * returns OASR_EINVAL.  A file that ends inside a page is decoded up to the last whole page.  The sample count follows
+ * returns OASR_EINVAL.  Chained files (logical streams one behind the other) come out as one signal, every link's
+ * samples in order; links that differ in sample rate or channel count are refused.  A file that ends inside a page is
+ * decoded up to the last whole page.  The sample count follows
  * the granule positions (start and end trimming).  oasr_vorbis_info parses the headers and walks the packets' first
  * bytes only.  oasr_vorbis_decode writes interleaved float32 samples (not clipped), oasr_vorbis_decode_mono the channel
  * mean (formed in double, rounded once).  `threads`: 0 = up to 16 host threads on packet ranges for long streams (a

@@ -9,10 +9,12 @@
 // any number of threads.
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <memory>
 #include <new>
 #include <string>
 #include <thread>
@@ -133,8 +135,13 @@ static inline uint32_t le32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2
 
 // `keep_bytes` false: only the packets' first byte and lengths are wanted (the sample count), so page bodies are neither
 // checked nor copied.  `flac`: the stream looked for is the FLAC mapping's (first packet 0x7f "FLAC") instead of Vorbis.
-static bool demux(const uint8_t* d, size_t n, Stream& s, std::string& err, bool keep_bytes = true, bool flac = false) {
-    size_t pos = 0;
+// `start` / `end_pos`: where the walk begins and where it ended (behind the stream's last page: the next link of a chained
+// file starts there); `none`: set when the walk failed only because no stream of the kind begins at or after `start`.
+static bool demux(const uint8_t* d, size_t n, Stream& s, std::string& err, bool keep_bytes = true, bool flac = false,
+                  size_t start = 0, size_t* end_pos = nullptr, bool* none = nullptr) {
+    size_t pos = start;
+    if (none) *none = false;
+    if (end_pos) *end_pos = n;
     bool have = false, in_packet = false, skipping = false, have_seq = false;
     uint32_t serial = 0, next_seq = 0;
     size_t cur_off = 0;
@@ -199,10 +206,16 @@ static bool demux(const uint8_t* d, size_t n, Stream& s, std::string& err, bool 
                 continue;
             }
         } else if (ser != serial) {
+            // streams multiplexed with this one all begin before its first data page; a stream of the same kind that
+            // begins later is the next link of a chain whose last page was not marked
+            const bool again = (htype & 2) && s.packets.size() > 3 &&
+                               (flac ? body_len >= 5 && memcmp(bp, "\x7f" "FLAC", 5) == 0
+                                     : body_len >= 7 && memcmp(bp, "\x01vorbis", 7) == 0);
+            if (again) break;
             pos = page_end;   // a multiplexed stream of another kind
             continue;
         } else if (htype & 2) {
-            break;   // a chained stream under the same serial number: the first one is what is decoded
+            break;   // the next link of a chain under the same serial number
         }
         if (have_seq && seq != next_seq) {
             err = "ogg: a page of the stream is missing";
@@ -248,7 +261,9 @@ static bool demux(const uint8_t* d, size_t n, Stream& s, std::string& err, bool 
         pos = page_end;
         if (htype & 4) break;
     }
+    if (end_pos) *end_pos = pos;
     if (!have) {
+        if (none) *none = true;
         const std::string want = flac ? "FLAC" : "Vorbis";
         err = other.empty() ? "ogg: no " + want + " stream found" : "ogg: the file holds " + other + ", not " + want;
         return false;
@@ -1026,8 +1041,9 @@ struct Plan {
     int64_t skip = 0, total = 0;   // samples dropped at the start, samples delivered
 };
 
-static bool open_stream(const uint8_t* d, size_t n, Plan& P, std::string& err, bool for_info = false) {
-    if (!demux(d, n, P.st, err, !for_info)) return false;
+static bool open_stream(const uint8_t* d, size_t n, Plan& P, std::string& err, bool for_info = false, size_t start = 0,
+                        size_t* end_pos = nullptr, bool* none = nullptr) {
+    if (!demux(d, n, P.st, err, !for_info, false, start, end_pos, none)) return false;
     if (!parse_headers(P.st, P.S, err)) return false;
     const Setup& S = P.S;
     int64_t c = 0;
@@ -1058,8 +1074,10 @@ static bool open_stream(const uint8_t* d, size_t n, Plan& P, std::string& err, b
     if (first_granule_packet >= 0) {
         const Packet& fp = P.st.packets[P.audio[first_granule_packet]];
         // the first page's granule position may state fewer samples than its packets produce: the excess is cut from
-        // the start - unless that page is also the last one, where the cut is at the end
-        if (!fp.eos_page && fp.granule >= 0) base = fp.granule - (P.centre[first_granule_packet] - c0);
+        // the start - unless that page is also the last one (marked as such, or simply the last there is), where the
+        // cut is at the end
+        const bool last_page = fp.eos_page || (size_t)P.audio[first_granule_packet] + 1 == P.st.packets.size();
+        if (!last_page && fp.granule >= 0) base = fp.granule - (P.centre[first_granule_packet] - c0);
     }
     P.skip = base < 0 ? -base : 0;
     if (P.skip > decoded) P.skip = decoded;
@@ -1161,6 +1179,58 @@ static void decode_all(const Plan& P, float* out, int threads) {
     decode_span<MONO>(P, a, b, out, 0, P.total, threads);
 }
 
+// ---- a chained file: logical streams one behind the other (RFC 3533 section 4), delivered as one signal ----
+struct Chain {
+    std::vector<std::unique_ptr<Plan>> links;
+    std::vector<int64_t> first;   // position of link i's first sample in the delivered signal
+    int64_t total = 0;
+    int rate = 0, channels = 0;
+};
+
+static bool open_chain(const uint8_t* d, size_t n, Chain& C, std::string& err, bool for_info = false) {
+    size_t pos = 0;
+    while (pos < n) {
+        std::unique_ptr<Plan> P(new Plan);
+        size_t end = n;
+        bool none = false;
+        if (!open_stream(d, n, *P, err, for_info, pos, &end, &none)) {
+            if (none && !C.links.empty()) break;   // whatever follows the last link is not a stream of this kind
+            return false;
+        }
+        if (C.links.empty()) {
+            C.rate = P->S.rate;
+            C.channels = P->S.channels;
+        } else if (P->S.rate != C.rate || P->S.channels != C.channels) {
+            char msg[160];
+            snprintf(msg, sizeof msg, "ogg: link %zu of the chained file is %d Hz with %d channel(s), the first one %d Hz with %d",
+                     C.links.size() + 1, P->S.rate, P->S.channels, C.rate, C.channels);
+            err = msg;
+            return false;
+        }
+        C.first.push_back(C.total);
+        C.total += P->total;
+        C.links.push_back(std::move(P));
+        if (end <= pos) break;
+        pos = end;
+    }
+    return true;
+}
+
+// the samples [first, first + count) of the delivered signal, from every link that holds some of them
+template <bool MONO>
+static void decode_chain(const Chain& C, int64_t first, int64_t count, float* out, int threads) {
+    const size_t width = MONO ? 1 : (size_t)C.channels;
+    for (size_t i = 0; i < C.links.size(); ++i) {
+        const Plan& P = *C.links[i];
+        const int64_t lo = std::max<int64_t>(first, C.first[i]) - C.first[i];
+        const int64_t hi = std::min<int64_t>(first + count, C.first[i] + P.total) - C.first[i];
+        if (lo >= hi || P.audio.size() < 2) continue;
+        size_t a, b;
+        packets_for(P, lo, hi - lo, a, b);
+        decode_span<MONO>(P, a, b, out + (size_t)(C.first[i] + lo - first) * width, lo, hi, threads);
+    }
+}
+
 }  // namespace vorbis
 }  // namespace oasr
 
@@ -1171,15 +1241,15 @@ extern "C" {
 int oasr_vorbis_info(const uint8_t* data, int64_t size, int32_t* sample_rate, int32_t* channels,
                      int64_t* samples_per_channel) {
     OASR_REQUIRE(data && size > 0 && sample_rate && channels && samples_per_channel, "vorbis_info: null pointer");
-    vorbis::Plan P;
+    vorbis::Chain C;
     std::string err;
-    if (!vorbis::open_stream(data, (size_t)size, P, err, true)) {
+    if (!vorbis::open_chain(data, (size_t)size, C, err, true)) {
         set_error("%s", err.c_str());
         return OASR_EINVAL;
     }
-    *sample_rate = P.S.rate;
-    *channels = P.S.channels;
-    *samples_per_channel = P.total;
+    *sample_rate = C.rate;
+    *channels = C.channels;
+    *samples_per_channel = C.total;
     return OASR_OK;
 }
 
@@ -1187,22 +1257,22 @@ static int vorbis_decode_any(const uint8_t* data, int64_t size, float* out, int6
                              int32_t threads, bool mono) {
     OASR_REQUIRE(data && size > 0 && out && written, "vorbis_decode: null pointer");
     OASR_REQUIRE(capacity >= 0, "vorbis_decode: negative capacity");
-    vorbis::Plan P;
+    vorbis::Chain C;
     std::string err;
-    if (!vorbis::open_stream(data, (size_t)size, P, err)) {
+    if (!vorbis::open_chain(data, (size_t)size, C, err)) {
         set_error("%s", err.c_str());
         return OASR_EINVAL;
     }
-    if (P.total > capacity) {
+    if (C.total > capacity) {
         set_error("vorbis_decode: output holds %lld samples per channel, the stream has %lld", (long long)capacity,
-                  (long long)P.total);
+                  (long long)C.total);
         return OASR_EINVAL;
     }
     if (mono)
-        vorbis::decode_all<true>(P, out, threads);
+        vorbis::decode_chain<true>(C, 0, C.total, out, threads);
     else
-        vorbis::decode_all<false>(P, out, threads);
-    *written = P.total;
+        vorbis::decode_chain<false>(C, 0, C.total, out, threads);
+    *written = C.total;
     return OASR_OK;
 }
 
@@ -1219,7 +1289,7 @@ int oasr_vorbis_decode_mono(const uint8_t* data, int64_t size, float* out, int64
 }  // extern "C"
 
 struct oasr_vorbis_stream {
-    vorbis::Plan plan;
+    vorbis::Chain chain;
 };
 
 extern "C" {
@@ -1233,28 +1303,26 @@ int oasr_vorbis_open(const uint8_t* data, int64_t size, oasr_vorbis_stream** str
         return OASR_EINVAL;
     }
     std::string err;
-    if (!vorbis::open_stream(data, (size_t)size, s->plan, err)) {
+    if (!vorbis::open_chain(data, (size_t)size, s->chain, err)) {
         delete s;
         set_error("%s", err.c_str());
         return OASR_EINVAL;
     }
-    *sample_rate = s->plan.S.rate;
-    *channels = s->plan.S.channels;
-    *samples_per_channel = s->plan.total;
+    *sample_rate = s->chain.rate;
+    *channels = s->chain.channels;
+    *samples_per_channel = s->chain.total;
     *stream = s;
     return OASR_OK;
 }
 
 int oasr_vorbis_decode_mono_range(const oasr_vorbis_stream* stream, int64_t first, int64_t count, float* out) {
     OASR_REQUIRE(stream && out, "vorbis_decode_mono_range: null pointer");
-    const vorbis::Plan& P = stream->plan;
-    OASR_REQUIRE(first >= 0 && count >= 0 && first + count <= P.total,
+    const vorbis::Chain& C = stream->chain;
+    OASR_REQUIRE(first >= 0 && count >= 0 && first + count <= C.total,
                  "vorbis_decode_mono_range: samples [%lld, %lld) of a stream of %lld", (long long)first,
-                 (long long)(first + count), (long long)P.total);
+                 (long long)(first + count), (long long)C.total);
     if (count == 0) return OASR_OK;
-    size_t a, b;
-    vorbis::packets_for(P, first, count, a, b);
-    vorbis::decode_span<true>(P, a, b, out, first, first + count, 0);
+    vorbis::decode_chain<true>(C, first, count, out, 0);
     return OASR_OK;
 }
 
@@ -1318,23 +1386,28 @@ int oasr_ogg_flac_unwrap(const uint8_t* data, int64_t size, uint8_t* out, int64_
 // stream decoded with the right code books the figure stays below 8.
 int oasr_vorbis_packet_tails(const uint8_t* data, int64_t size, int32_t* tails, int64_t capacity, int64_t* packets) {
     OASR_REQUIRE(data && size > 0 && tails && packets, "vorbis_packet_tails: null pointer");
-    vorbis::Plan P;
+    vorbis::Chain C;
     std::string err;
-    if (!vorbis::open_stream(data, (size_t)size, P, err)) {
+    if (!vorbis::open_chain(data, (size_t)size, C, err)) {
         set_error("%s", err.c_str());
         return OASR_EINVAL;
     }
-    OASR_REQUIRE((int64_t)P.audio.size() <= capacity, "vorbis_packet_tails: %lld packets, room for %lld",
-                 (long long)P.audio.size(), (long long)capacity);
-    vorbis::Work W;
-    W.init(P.S);
-    for (size_t i = 0; i < P.audio.size(); ++i) {
-        const vorbis::Packet& pk = P.st.packets[P.audio[i]];
-        int64_t t = 0;
-        vorbis::decode_packet(P.S, P.st.body.data() + pk.off, pk.len, W, &t);
-        tails[i] = (int32_t)t;
+    int64_t n = 0;
+    for (const auto& link : C.links) n += (int64_t)link->audio.size();
+    OASR_REQUIRE(n <= capacity, "vorbis_packet_tails: %lld packets, room for %lld", (long long)n, (long long)capacity);
+    n = 0;
+    for (const auto& link : C.links) {
+        const vorbis::Plan& P = *link;
+        vorbis::Work W;
+        W.init(P.S);
+        for (size_t i = 0; i < P.audio.size(); ++i) {
+            const vorbis::Packet& pk = P.st.packets[P.audio[i]];
+            int64_t t = 0;
+            vorbis::decode_packet(P.S, P.st.body.data() + pk.off, pk.len, W, &t);
+            tails[n++] = (int32_t)t;
+        }
     }
-    *packets = (int64_t)P.audio.size();
+    *packets = n;
     return OASR_OK;
 }
 

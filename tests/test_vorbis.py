@@ -168,6 +168,51 @@ def test_long_stream_any_thread_count_and_any_sample_range():
         L.oasr_vorbis_close(h)
 
 
+def test_chained_streams_come_out_as_one_signal(golden_dir):
+    """Logical streams one behind the other (a chained file: concatenated recordings, captured broadcasts) are one
+    signal: every link's samples in order, whole or by ranges that cross the joins, on any thread count; links with
+    different setups (block sizes, residue types, books) are fine, links that differ in rate or channel count are
+    refused by name rather than cut off; the real stream behind itself decodes to itself twice."""
+    a_cfg = vt.Config(channels=2, pattern="LSSL", seed=1, residue_type=2, coupled=True)
+    b_cfg = vt.Config(channels=2, pattern="LL", seed=2, residue_type=1, coupled=True, book_kind="table", bs0=128, bs1=512,
+                      trim_end=True)
+    a, b = vt.encode(_signal(7000, 2, 1), a_cfg), vt.encode(_signal(5000, 2, 2), b_cfg)
+    want = np.concatenate([a.expected, b.expected, a.expected])
+    for eos in (True, False):
+        data = vt.with_serial(a.data, 11, eos) + vt.with_serial(b.data, 12, eos) + vt.with_serial(a.data, 13)
+        out, rate = _decode(data)
+        assert rate == 16000 and out.shape == want.shape
+        assert np.abs(out - want).max() < 2e-6
+        assert len(_tails(data)) == 2 * len(a.blocks) + len(b.blocks) and _tails(data).min() >= 0
+    for threads in (2, 5):
+        np.testing.assert_array_equal(_decode(data, threads=threads)[0], out)
+    mono, _ = _decode(data, mono=True)
+    L = _hip.lib()
+    d = np.frombuffer(data, dtype=np.uint8)
+    h, r, c, t = C.c_void_p(), C.c_int32(), C.c_int32(), C.c_int64()
+    _hip.check(L.oasr_vorbis_open(d.ctypes.data, d.size, C.byref(h), C.byref(r), C.byref(c), C.byref(t)))
+    try:
+        assert t.value == want.shape[0]
+        for first, count in ((0, t.value), (a.total - 10, 20), (a.total, b.total), (a.total - 1, b.total + 2), (a.total + b.total - 300, 301),
+                             (a.total + b.total, 1), (t.value - 1, 1), (3, 0)):
+            got = np.zeros(count, dtype=np.float32)
+            _hip.check(L.oasr_vorbis_decode_mono_range(h, first, count, got.ctypes.data))
+            np.testing.assert_array_equal(got, mono[first: first + count])
+    finally:
+        L.oasr_vorbis_close(h)
+    # a link of another shape: named, not dropped
+    other = vt.encode(_signal(3000, 1, 3)[:, 0], vt.Config(pattern="L", seed=3))
+    with pytest.raises(_hip.OasrError, match="link 2 of the chained file is 16000 Hz with 1 channel"):
+        _decode(a.data + vt.with_serial(other.data, 99))
+    # junk after the last link ends the chain quietly
+    np.testing.assert_array_equal(_decode(a.data + b"\x00" * 100 + b"OggS" + b"\x01" * 10)[0], _decode(a.data)[0])
+    # the real stream twice (the same serial number again: tolerated)
+    real = (golden_dir / "mathjax_invalid_keypress.ogg").read_bytes()
+    x, _ = _decode(real)
+    xx, _ = _decode(real + real)
+    np.testing.assert_array_equal(xx, np.concatenate([x, x]))
+
+
 def test_damaged_and_foreign_streams_are_refused_or_cut_short(tmp_path):
     enc = vt.encode(_signal(9000, 1, 9)[:, 0], vt.Config(pattern="SSL", seed=9, bs0=64, bs1=256, partition_size=16))
     data = vt.ogg_pages(enc.packets, enc.granules, per_page=[1, 1, 1] + [10] * len(enc.packets))   # several audio pages

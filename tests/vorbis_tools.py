@@ -471,6 +471,25 @@ def ogg_pages(packets: list[bytes], granules: list[int], serial=0x1234, per_page
     return bytes(out)
 
 
+def with_serial(data: bytes, serial: int, eos: bool = True) -> bytes:
+    """The same pages under another stream serial number (checksums recomputed) - for chained files, whose links each
+    carry their own.  `eos` False: the last page loses its end-of-stream mark (a chain some writers leave that way)."""
+    out, pos = bytearray(), 0
+    while pos < len(data):
+        assert data[pos:pos + 4] == b"OggS"
+        nseg = data[pos + 26]
+        size = 27 + nseg + sum(data[pos + 27: pos + 27 + nseg])
+        page = bytearray(data[pos: pos + size])
+        page[14:18] = struct.pack("<I", serial)
+        if not eos:
+            page[5] &= ~4
+        page[22:26] = bytes(4)
+        page[22:26] = struct.pack("<I", ogg_crc(bytes(page)))
+        out += page
+        pos += size
+    return bytes(out)
+
+
 # ---- the encoder ----
 @dataclass
 class Config:
